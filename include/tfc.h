@@ -1,0 +1,248 @@
+/*
+ * tfc.h - C ABI of libtfc: MI355X (gfx950) kernels for eigenn's tensor-field convolution
+ * message-passing layer.
+ *
+ * The reference (mjwen/matten, package `eigenn`) is pure Python and has no FFI of its own:
+ * every number on this path is produced by e3nn / torch / torch_scatter calls.  Each entry
+ * point below therefore cites the reference CALL SITE it replaces (paths relative to the
+ * reference root).  The reference-side binding a maintainer would add is a ctypes stub; see
+ * INTEGRATION.md.
+ *
+ * Conventions
+ *   - every function returns 0 on success, a negative TFC_E* code otherwise; the message of the
+ *     last failure on the calling thread is available from tfc_last_error().
+ *   - all tensor arguments are DEVICE pointers to contiguous row-major buffers owned by the
+ *     caller (PyTorch).  fp32 data, int64 indices as delivered by the reference's data
+ *     pipeline (eigenn/data/_dtype.py:3-4), int32 for the orderings this library builds.
+ *   - the library never allocates or frees device memory inside a compute call: scratch comes
+ *     in through `workspace` arguments whose size the *_workspace_* functions report.  Only
+ *     tfc_conv_plan_create() allocates (small constant tables) and tfc_conv_plan_destroy()
+ *     frees them.
+ *   - all launches are asynchronous on the caller's `stream` (a hipStream_t passed as void*,
+ *     0 = the null stream).  No call synchronises the host.  Plans are immutable after
+ *     creation, so calls are re-entrant across host threads and streams; the only global
+ *     mutable state is the thread-local error string.
+ *   - a feature row with irreps sum_b mul_b x (l_b, p_b) is the concatenation of the blocks b,
+ *     each stored row-major as [mul_b][2 l_b + 1] (e3nn layout).
+ */
+#ifndef TFC_H
+#define TFC_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TFC_OK 0
+#define TFC_EINVAL (-1)       /* null pointer, negative size, inconsistent table ... */
+#define TFC_EUNSUPPORTED (-2) /* irreps outside what the kernels are built for (l > 3, ...) */
+#define TFC_ELAUNCH (-3)      /* a HIP call or kernel launch failed */
+#define TFC_ENOMEM (-4)
+
+#define TFC_LMAX 3
+
+typedef void* tfc_stream_t;
+typedef struct tfc_conv_plan tfc_conv_plan;
+
+int tfc_version(void);
+const char* tfc_last_error(void);
+
+/* ------------------------------------------------------------------------------------------
+ * Host-only helper: real Clebsch-Gordan tensor C[m1][m2][m3] (fp64, unit Frobenius norm) in
+ * the basis of the spherical harmonics below.  Replaces e3nn.o3.wigner_3j as used inside
+ * o3.TensorProduct (eigenn/nn/utils.py:231-238).  `out` is a HOST buffer of
+ * (2l1+1)(2l2+1)(2l3+1) doubles.
+ */
+int tfc_real_cg(int l1, int l2, int l3, double* out);
+
+/* ------------------------------------------------------------------------------------------
+ * Edge ordering.  Groups the edges by `key` (a row of edge_index) so that the convolution can
+ * reduce over each node's edges in registers instead of scatter_add_'s global atomics
+ * (eigenn/nn/utils.py:351-357, called at eigenn/nn/point_conv.py:173-175).
+ *
+ *   key, other : [E] int64   the grouping row of edge_index and the opposite row
+ *   row_ptr    : [N+1] int32 out: edges of node n are sorted positions row_ptr[n]..row_ptr[n+1]
+ *   eid        : [E] int32   out: original edge id at each sorted position (ascending inside a
+ *                            node => the summation order, hence the result, is deterministic)
+ *   nbr        : [E] int32   out: other[eid[k]]
+ *   status     : [1] int32   out: 0, or 1 if any index was outside [0, N) (such edges are dropped
+ *                            from the ordering; the caller decides when to read the flag)
+ *   workspace  : tfc_csr_workspace_bytes(N, E) bytes
+ */
+int64_t tfc_csr_workspace_bytes(int64_t n_nodes, int64_t n_edges);
+int tfc_csr_build(const int64_t* key, const int64_t* other, int64_t n_edges, int64_t n_nodes,
+                  int32_t* row_ptr, int32_t* eid, int32_t* nbr, int32_t* status, void* workspace,
+                  tfc_stream_t stream);
+
+/* The unfused route, for callers that materialise per-edge messages and sum them afterwards
+ * (scatter_add, eigenn/nn/utils.py:351-357, and its backward, a row gather):
+ *   tfc_segment_sum: out[n] = sum_{k in rows(n)} src[eid[k]]   src [E,d] -> out [N,d], no atomics
+ *   tfc_gather_rows: out[r] = src[index[r]]                    src [n_src,d], index [n_rows] int64
+ */
+int tfc_segment_sum(const float* src, const int32_t* row_ptr, const int32_t* eid, int64_t n_nodes,
+                    int32_t d, float* out, tfc_stream_t stream);
+int tfc_gather_rows(const float* src, const int64_t* index, int64_t n_rows, int64_t n_src, int32_t d,
+                    float* out, tfc_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * 'uvu' tensor product with per-edge weights, fused with the gather of sender features and
+ * the sum over each receiver's edges.
+ *
+ * Replaces, in one kernel: node_feats[edge_src] (eigenn/nn/point_conv.py:82), the e3nn
+ * o3.TensorProduct(..., 'uvu', shared_weights=False) call (eigenn/nn/utils.py:265), scatter_add
+ * (eigenn/nn/point_conv.py:173-175) and the 1/sqrt(avg_num_neighbors) scale (:177-178).
+ *
+ *   out[n, out_off_p + u*(2l3+1) + m3] = scale * coeff_p * sum_{e : centre(e) = n} w[e, w_off_p + u]
+ *        * sum_{m1,m2} C^{l1 l2 l3}[m1,m2,m3] * x[nbr(e), x_off_p + u*(2l1+1) + m1] * y[e, y_off_p + m2]
+ *
+ * One tfc_path per e3nn instruction, in the instruction (= weight slot) order built at
+ * eigenn/nn/utils.py:205-229.  Restrictions (TFC_EUNSUPPORTED otherwise): l1,l2,l3 <= TFC_LMAX,
+ * the edge-attribute block of every path has multiplicity 1, and every path owns its output
+ * block (both hold for every UVUTensorProduct the reference builds from spherical-harmonic
+ * edge attributes).
+ */
+typedef struct tfc_path {
+    int32_t l1, l2, l3;
+    int32_t mul;     /* channels u of the in1 block (= multiplicity of the output block) */
+    int32_t x_off;   /* offset of the in1 block inside a node-feature row */
+    int32_t y_off;   /* offset of the in2 block inside an edge-attribute row */
+    int32_t out_off; /* offset of the output block inside an output row */
+    int32_t w_off;   /* offset of this path's `mul` weights inside a per-edge weight row */
+    float coeff;     /* sqrt(alpha): e3nn's path normalisation (= sqrt(2 l3 + 1) here) */
+} tfc_path;
+
+int tfc_conv_plan_create(const tfc_path* paths, int32_t n_paths, int32_t d_in, int32_t d_sh,
+                         int32_t d_out, int32_t w_numel, tfc_conv_plan** plan);
+int tfc_conv_plan_destroy(tfc_conv_plan* plan);
+
+/* floats of scratch a forward / backward call needs for E edges */
+int64_t tfc_conv_workspace_floats(const tfc_conv_plan* plan, int64_t n_edges, int need_dy);
+
+/* Forward.  (row_ptr, eid, nbr) = tfc_csr_build(key = edge_index[1] (receiver), other =
+ * edge_index[0] (sender)).  x [N, d_in], y [E, d_sh], w [E, w_numel] in the caller's edge order;
+ * out [N, d_out] is fully overwritten. */
+int tfc_conv_fwd(const tfc_conv_plan* plan, const float* x, const float* y, const float* w,
+                 const int32_t* row_ptr, const int32_t* eid, const int32_t* nbr, int64_t n_nodes,
+                 int64_t n_edges, float scale, float* out, float* workspace, tfc_stream_t stream);
+
+/* Backward of the above (what autograd derives in the reference).  Here the edges are grouped
+ * by SENDER: (row_ptr, eid, nbr) = tfc_csr_build(key = edge_index[0], other = edge_index[1]).
+ * gout [N, d_out]; dx [N, d_in] and dw [E, w_numel] are fully overwritten; dy [E, d_sh] is
+ * overwritten when non-null (pass null when the edge attributes need no gradient). */
+int tfc_conv_bwd(const tfc_conv_plan* plan, const float* x, const float* y, const float* w,
+                 const float* gout, const int32_t* row_ptr, const int32_t* eid, const int32_t* nbr,
+                 int64_t n_nodes, int64_t n_edges, float scale, float* dx, float* dw, float* dy,
+                 float* workspace, tfc_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Per-edge encoders.
+ *
+ * Replaces with_edge_vectors (eigenn/nn/_nequip.py:214-266), o3.SphericalHarmonics(irreps,
+ * normalize=True, normalization="component") (:167-175) and BesselBasis x PolynomialCutoff
+ * (:117-128, :63-78, :206-208) in one pass over the edges:
+ *
+ *   vec[e] = pos[ei[1,e]] - pos[ei[0,e]] + shift[e] @ cell[batch[ei[0,e]]]
+ *   sh [e, l*l + m]  = Y_l^m(vec/|vec|), l = 0..lmax, component normalisation
+ *   emb[e, n]        = (2/r_max) sin(bw[n] |vec| / r_max) / |vec| * env_p(|vec| / r_max) * (|vec| < r_max)
+ *
+ * edge_index [2,E] int64; shift [E,3] (may be null: no periodic images); cell [G,3,3] (null iff
+ * shift is null); batch [N] int64 (may be null when G == 1); bw [n_basis] the (trainable) Bessel
+ * frequencies.  Outputs vec [E,3], len [E], sh [E,(lmax+1)^2], emb [E,n_basis]; sh or emb may be
+ * null to skip that encoder.  When `pos` is null the edge vectors are taken from `vec` as given
+ * (the reference's cached EDGE_VECTORS branch, _nequip.py:224-229) and `len`, when non-null, is
+ * read as their lengths.
+ */
+int tfc_edge_encode_fwd(const float* pos, const int64_t* edge_index, const float* shift,
+                        const float* cell, const int64_t* batch, int64_t n_edges, int64_t n_nodes,
+                        int64_t n_graphs, int32_t lmax, const float* bw, int32_t n_basis,
+                        float r_max, float p, float* vec, float* len, float* sh, float* emb,
+                        tfc_stream_t stream);
+
+/* Backward: per-edge gradient of the edge vector from the gradients of sh and emb (either may
+ * be null), and the gradient of the Bessel frequencies.
+ *   dvec [E,3] out;  dbw_partial [n_blocks, n_basis] out (null to skip), where
+ *   n_blocks = tfc_edge_bwd_blocks(E): the caller sums the rows (deterministic two-stage sum). */
+int64_t tfc_edge_bwd_blocks(int64_t n_edges);
+int tfc_edge_encode_bwd(const float* vec, const float* len, int64_t n_edges, int32_t lmax,
+                        const float* bw, int32_t n_basis, float r_max, float p, const float* dsh,
+                        const float* demb, const float* dvec_add, const float* dlen, float* dvec,
+                        float* dbw_partial, tfc_stream_t stream);
+
+/* Scatter of the per-edge vector gradient to positions (and cells):
+ *   dpos[n] = sum_{e: ei[1,e]=n} dvec[e] - sum_{e: ei[0,e]=n} dvec[e]
+ * using the two orderings of tfc_csr_build (no atomics).  (rp_dst, eid_dst) group by ei[1],
+ * (rp_src, eid_src) by ei[0].  dpos [N,3] is overwritten. */
+int tfc_edge_vec_bwd(const float* dvec, const int32_t* rp_src, const int32_t* eid_src,
+                     const int32_t* rp_dst, const int32_t* eid_dst, int64_t n_nodes, float* dpos,
+                     tfc_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Dense contractions on the fp32 matrix cores (v_mfma_f32_32x32x2_f32: exact fp32 fmaf chains).
+ *
+ * One strided GEMM serves the radial FullyConnectedNet (eigenn/nn/utils.py:247-252,262), the
+ * o3.Linear channel mixers (eigenn/nn/point_conv.py:56-61,79 and :130-135,180) and the
+ * FullyConnectedTensorProduct self connection (:159-164,185-188), forward and backward:
+ *
+ *   C[addrC(r,j)] (+)= epilogue( alpha * sum_k A1[addrA1(r,k)] * (A2 ? A2[addrA2(r,k)] : 1) * B[addrB(k,j)] )
+ *
+ * Every address is a sum of per-index maps  f(t) = (t / (d1*d2))*s0 + ((t / d2) % d1)*s1 + (t % d2)*s2,
+ * which is what lets one kernel walk e3nn's [node][mul][2l+1] blocks without materialising
+ * transposes or outer products.
+ */
+typedef struct tfc_imap {
+    int32_t d1, d2;      /* >= 1 */
+    int64_t s0, s1, s2;  /* element strides */
+} tfc_imap;
+
+typedef struct tfc_gemm_desc {
+    int64_t m, n, k;
+    const float* a1;
+    const float* a2; /* optional second factor of the A operand (null: none) */
+    const float* b;
+    float* c;
+    tfc_imap a1_r, a1_k, a2_r, a2_k, b_k, b_j, c_r, c_j;
+    float alpha;
+    int32_t accumulate; /* 1: C += ..., 0: C = ... */
+    int32_t epilogue;   /* TFC_EPI_* */
+    const float* aux;   /* TFC_EPI_SSP_GRAD: activation output h, addressed like C */
+    float act_cst;      /* normalize2mom constant of the activation */
+} tfc_gemm_desc;
+
+#define TFC_EPI_NONE 0
+#define TFC_EPI_SSP 1      /* v = act_cst * (softplus(v) - ln 2)                              */
+#define TFC_EPI_SSP_GRAD 2 /* v = v * d act/d pre, recovered from aux = act output            */
+
+int tfc_gemm(const tfc_gemm_desc* desc, tfc_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Gate non-linearity (e3nn.nn.Gate built at eigenn/nn/utils.py:134-140, applied at
+ * eigenn/nn/point_conv.py:339).  The input row is [scalars | gates | gated]; the output row is
+ * [act(scalars) | gate * gated].  One tfc_gate_seg per run of columns sharing an activation.
+ */
+#define TFC_ACT_IDENTITY 0
+#define TFC_ACT_SSP 1
+#define TFC_ACT_SILU 2
+#define TFC_ACT_TANH 3
+#define TFC_ACT_ABS 4
+#define TFC_ACT_SIGMOID 5
+
+typedef struct tfc_gate_seg {
+    int32_t in_off;   /* first input column of the segment */
+    int32_t out_off;  /* first output column */
+    int32_t count;    /* number of scalar channels (scalars) or gated channels (mul) */
+    int32_t dim;      /* 1 for scalars; 2l+1 for a gated block */
+    int32_t gate_off; /* gated block: input column of its first gate; scalars: -1 */
+    int32_t act;      /* TFC_ACT_* applied to the scalar / to the gate */
+    float cst;        /* normalize2mom constant of that activation */
+} tfc_gate_seg;
+
+int tfc_gate_fwd(const tfc_gate_seg* segs, int32_t n_segs, const float* x, int64_t n_rows,
+                 int32_t d_in, int32_t d_out, float* out, tfc_stream_t stream);
+int tfc_gate_bwd(const tfc_gate_seg* segs, int32_t n_segs, const float* x, const float* gout,
+                 int64_t n_rows, int32_t d_in, int32_t d_out, float* dx, tfc_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TFC_H */

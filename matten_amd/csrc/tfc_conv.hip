@@ -1,0 +1,638 @@
+// Fused gather + 'uvu' tensor product + per-node sum, forward and backward, for gfx950.
+//
+// Replaces the chain  node_feats[edge_src] -> o3.TensorProduct('uvu', per-edge weights) ->
+// scatter_add -> /sqrt(avg_num_neighbors)  of the reference (eigenn/nn/point_conv.py:82,
+// eigenn/nn/utils.py:265, eigenn/nn/point_conv.py:173-178) and what autograd derives from it.
+//
+// Data flow:
+//   * edges are grouped by their centre node (receiver for forward, sender for backward) by
+//     tfc_csr_build; one 64-lane wave owns one (centre node, work item) and keeps the sums of
+//     that item in registers over all edges of the node: no atomics, fixed summation order.
+//   * lane = channel u.  Everything that does not depend on u is wave-uniform and is kept out
+//     of the vector registers: the edge ids come in through scalar loads, and the contraction
+//     of the Clebsch-Gordan tensor with the edge's spherical harmonics,
+//         M_e[m1][m3] = sum_m2 C[m1][m2][m3] * y[e][m2],
+//     is computed once per edge by a small pre-pass and then read through the scalar cache,
+//     so the inner loop is (2l1+1)(2l3+1) v_fma with an SGPR operand per edge and path.
+//   * HBM traffic is the per-edge weight row (read once, fully coalesced: 256 B per wave and
+//     path); neighbour rows are gathered from L2 / Infinity Cache.
+#include "tfc_common.h"
+
+#include <algorithm>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <new>
+#include <tuple>
+#include <vector>
+
+namespace {
+
+struct PathDev {
+    int l1, l2, l3, mul;
+    int x_off, y_off, out_off, w_off;
+    int m_off;   // offset of the (l1,l2,l3,y_off) block in an M row
+    int cg_off;  // offset of the dense C[m1][m2][m3] table of that triple
+    int py_off;  // first partial-dy slot of this path (chunk 0)
+    float coeff;
+};
+
+struct FwdItem {
+    int path, chunk;
+};
+
+struct BwdItem {
+    int grp_start, grp_count;  // range in grp_paths: the paths reading this in1 block
+    int chunk, l1;
+    int x_off, mul;
+};
+
+struct MEnt {
+    int cg_row;  // offset in cgm of the n2 coefficients of this (m1, m3)
+    int y_off;
+    int n2;  // 0 for padding entries
+};
+
+}  // namespace
+
+struct tfc_conv_plan {
+    int n_paths, d_in, d_sh, d_out, w_numel;
+    int msz;  // floats per edge of the M buffer (multiple of 4)
+    int py;   // floats per edge of the partial-dy buffer
+    int n_fwd_items, n_bwd_items;
+    int device;
+    PathDev* paths;
+    FwdItem* fwd_items;
+    BwdItem* bwd_items;
+    int* grp_paths;
+    MEnt* ments;
+    float* cgm;  // per (m1,m3): C[m1][0..n2)[m3]
+    float* cgd;  // dense C[m1][m2][m3]
+    int* ylist_ptr;  // [d_sh + 1]
+    int* ylist;      // partial-dy columns contributing to each edge-attribute column
+    void* blob;
+};
+
+// ------------------------------------------------------------------------------------------
+// M pre-pass: M[k][j] for sorted position k and M-row entry j.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void tfc_m_prepass_kernel(const float* __restrict__ y,
+                                                            const int* __restrict__ eid,
+                                                            const MEnt* __restrict__ ments,
+                                                            const float* __restrict__ cgm, long n_edges,
+                                                            int msz, int d_sh, float* __restrict__ M) {
+    const long total = n_edges * (long)msz;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (long)gridDim.x * blockDim.x) {
+        const long k = i / msz;
+        const int j = (int)(i - k * msz);
+        const MEnt me = ments[j];
+        const float* yr = y + (long)eid[k] * d_sh + me.y_off;
+        float v = 0.f;
+        for (int m2 = 0; m2 < me.n2; ++m2) v = fmaf(cgm[me.cg_row + m2], yr[m2], v);
+        M[i] = v;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Forward
+// ------------------------------------------------------------------------------------------
+template <int L1, int L3, int UNR>
+__device__ __forceinline__ void fwd_edges(const float* __restrict__ xb, const float* __restrict__ wb,
+                                          const float* __restrict__ Mb, const int* __restrict__ eid,
+                                          const int* __restrict__ nbr, int k, int d_in, int w_numel,
+                                          int msz, float (&acc)[2 * L3 + 1]) {
+    constexpr int D1 = 2 * L1 + 1, D3 = 2 * L3 + 1;
+    float xv[UNR][D1], wv[UNR];
+#pragma unroll
+    for (int j = 0; j < UNR; ++j) {
+        const int e = eid[k + j];
+        const int s = nbr[k + j];
+        const float* xr = xb + (size_t)s * d_in;
+#pragma unroll
+        for (int m1 = 0; m1 < D1; ++m1) xv[j][m1] = xr[m1];
+        wv[j] = wb[(size_t)e * w_numel];
+    }
+#pragma unroll
+    for (int j = 0; j < UNR; ++j) {
+        const float* Mk = Mb + (size_t)(k + j) * msz;
+#pragma unroll
+        for (int m3 = 0; m3 < D3; ++m3) {
+            float z = 0.f;
+#pragma unroll
+            for (int m1 = 0; m1 < D1; ++m1) z = fmaf(Mk[m1 * D3 + m3], xv[j][m1], z);
+            acc[m3] = fmaf(wv[j], z, acc[m3]);
+        }
+    }
+}
+
+template <int L1, int L3>
+__device__ __forceinline__ void fwd_item(const float* __restrict__ x, const float* __restrict__ w,
+                                         const float* __restrict__ M, const int* __restrict__ eid,
+                                         const int* __restrict__ nbr, int beg, int end, const PathDev p,
+                                         int u, bool active, int node, int d_in, int d_out, int w_numel,
+                                         int msz, float scale, float* __restrict__ out) {
+    constexpr int D1 = 2 * L1 + 1, D3 = 2 * L3 + 1;
+    const int uu = active ? u : 0;  // idle lanes shadow channel 0: valid addresses, nothing stored
+    const float* xb = x + p.x_off + uu * D1;
+    const float* wb = w + p.w_off + uu;
+    const float* Mb = M + p.m_off;
+    float acc[D3];
+#pragma unroll
+    for (int m3 = 0; m3 < D3; ++m3) acc[m3] = 0.f;
+    int k = beg;
+    for (; k + 4 <= end; k += 4) fwd_edges<L1, L3, 4>(xb, wb, Mb, eid, nbr, k, d_in, w_numel, msz, acc);
+    for (; k < end; ++k) fwd_edges<L1, L3, 1>(xb, wb, Mb, eid, nbr, k, d_in, w_numel, msz, acc);
+    if (active) {
+        const float cs = p.coeff * scale;
+        float* o = out + (size_t)node * d_out + p.out_off + u * D3;
+#pragma unroll
+        for (int m3 = 0; m3 < D3; ++m3) o[m3] = cs * acc[m3];
+    }
+}
+
+__global__ __launch_bounds__(256) void tfc_conv_fwd_kernel(
+    const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ M,
+    const int* __restrict__ row_ptr, const int* __restrict__ eid, const int* __restrict__ nbr,
+    const PathDev* __restrict__ paths, const FwdItem* __restrict__ items, int n_items, long n_tasks,
+    int d_in, int d_out, int w_numel, int msz, float scale, float* __restrict__ out) {
+    const unsigned vb = tfc_xcd_remap(blockIdx.x, gridDim.x);
+    const int wave = tfc_uniform((int)(threadIdx.x >> 6));
+    const int lane = threadIdx.x & 63;
+    const long task = (long)vb * 4 + wave;
+    if (task >= n_tasks) return;
+    const int node = (int)(task / n_items);
+    const int item = (int)(task - (long)node * n_items);
+    const FwdItem it = items[item];
+    const PathDev p = paths[it.path];
+    const int u = it.chunk * 64 + lane;
+    const bool active = u < p.mul;
+    const int beg = tfc_uniform(row_ptr[node]);
+    const int end = tfc_uniform(row_ptr[node + 1]);
+
+#define TFC_FWD_CASE(A, B)                                                                          \
+    case (A)*4 + (B):                                                                               \
+        fwd_item<A, B>(x, w, M, eid, nbr, beg, end, p, u, active, node, d_in, d_out, w_numel, msz, \
+                       scale, out);                                                                 \
+        break;
+    switch (p.l1 * 4 + p.l3) {
+        TFC_FWD_CASE(0, 0) TFC_FWD_CASE(0, 1) TFC_FWD_CASE(0, 2) TFC_FWD_CASE(0, 3)
+        TFC_FWD_CASE(1, 0) TFC_FWD_CASE(1, 1) TFC_FWD_CASE(1, 2) TFC_FWD_CASE(1, 3)
+        TFC_FWD_CASE(2, 0) TFC_FWD_CASE(2, 1) TFC_FWD_CASE(2, 2) TFC_FWD_CASE(2, 3)
+        TFC_FWD_CASE(3, 0) TFC_FWD_CASE(3, 1) TFC_FWD_CASE(3, 2) TFC_FWD_CASE(3, 3)
+        default: break;
+    }
+#undef TFC_FWD_CASE
+}
+
+// ------------------------------------------------------------------------------------------
+// Backward.  Centre node = sender: its own row x[n] is fixed for the whole item, the upstream
+// gradient rows gout[receiver] are gathered.
+// ------------------------------------------------------------------------------------------
+template <int L1, int L2, int L3, bool NEED_DY>
+__device__ __forceinline__ void bwd_path(const float* __restrict__ w, const float* __restrict__ gout,
+                                         const float* __restrict__ M, const float* __restrict__ cgd,
+                                         const int* __restrict__ eid, const int* __restrict__ nbr,
+                                         int beg, int end, const PathDev p, int u, int uu, bool active,
+                                         int d_out, int w_numel, int msz, int py, float scale,
+                                         const float (&xv)[2 * L1 + 1], float (&gx)[2 * L1 + 1],
+                                         float* __restrict__ dw, float* __restrict__ dyp, int chunk) {
+    constexpr int D1 = 2 * L1 + 1, D2 = 2 * L2 + 1, D3 = 2 * L3 + 1;
+    const float cs = p.coeff * scale;
+    const float* gb = gout + p.out_off + uu * D3;
+    const float* wb = w + p.w_off + uu;
+    float* dwb = dw + p.w_off + uu;
+    const float* Mb = M + p.m_off;
+
+    // P[m2][m3] = sum_m1 C[m1][m2][m3] * x[n][u][m1]: fixed for the item, used for d/dy
+    float P[NEED_DY ? D2 : 1][NEED_DY ? D3 : 1];
+    if (NEED_DY) {
+        const float* C = cgd + p.cg_off;
+#pragma unroll
+        for (int m2 = 0; m2 < D2; ++m2)
+#pragma unroll
+            for (int m3 = 0; m3 < D3; ++m3) {
+                float s = 0.f;
+#pragma unroll
+                for (int m1 = 0; m1 < D1; ++m1) s = fmaf(C[(m1 * D2 + m2) * D3 + m3], xv[m1], s);
+                P[m2][m3] = active ? s : 0.f;
+            }
+    }
+
+    for (int k = beg; k < end; ++k) {
+        const int e = eid[k];
+        const int d = nbr[k];
+        const float* gr = gb + (size_t)d * d_out;
+        float g[D3];
+#pragma unroll
+        for (int m3 = 0; m3 < D3; ++m3) g[m3] = cs * gr[m3];
+        const float wv = wb[(size_t)e * w_numel];
+        const float* Mk = Mb + (size_t)k * msz;
+        float gw = 0.f;
+#pragma unroll
+        for (int m1 = 0; m1 < D1; ++m1) {
+            float t = 0.f;
+#pragma unroll
+            for (int m3 = 0; m3 < D3; ++m3) t = fmaf(Mk[m1 * D3 + m3], g[m3], t);
+            gw = fmaf(xv[m1], t, gw);
+            gx[m1] = fmaf(wv, t, gx[m1]);
+        }
+        if (active) dwb[(size_t)e * w_numel] = gw;
+        if (NEED_DY) {
+            float* dq = dyp + (size_t)e * py + p.py_off + chunk * D2;
+#pragma unroll
+            for (int m2 = 0; m2 < D2; ++m2) {
+                float q = 0.f;
+#pragma unroll
+                for (int m3 = 0; m3 < D3; ++m3) q = fmaf(P[m2][m3], g[m3], q);
+                q = tfc_wave_sum(wv * q);  // idle lanes hold P = 0
+                if ((threadIdx.x & 63) == 0) dq[m2] = q;
+            }
+        }
+    }
+}
+
+template <int L1, bool NEED_DY>
+__device__ __forceinline__ void bwd_item(const float* __restrict__ x, const float* __restrict__ w,
+                                         const float* __restrict__ gout, const float* __restrict__ M,
+                                         const float* __restrict__ cgd, const int* __restrict__ eid,
+                                         const int* __restrict__ nbr, const PathDev* __restrict__ paths,
+                                         const int* __restrict__ grp_paths, const BwdItem it, int beg,
+                                         int end, int node, int lane, int d_in, int d_out, int w_numel,
+                                         int msz, int py, float scale, float* __restrict__ dx,
+                                         float* __restrict__ dw, float* __restrict__ dyp) {
+    constexpr int D1 = 2 * L1 + 1;
+    const int u = it.chunk * 64 + lane;
+    const bool active = u < it.mul;
+    const int uu = active ? u : 0;
+    float xv[D1], gx[D1];
+    const float* xr = x + (size_t)node * d_in + it.x_off + uu * D1;
+#pragma unroll
+    for (int m1 = 0; m1 < D1; ++m1) {
+        xv[m1] = xr[m1];
+        gx[m1] = 0.f;
+    }
+    for (int gi = 0; gi < it.grp_count; ++gi) {
+        const PathDev p = paths[grp_paths[it.grp_start + gi]];
+#define TFC_BWD_CASE(B, C)                                                                            \
+    case (B)*4 + (C):                                                                                 \
+        bwd_path<L1, B, C, NEED_DY>(w, gout, M, cgd, eid, nbr, beg, end, p, u, uu, active, d_out,     \
+                                    w_numel, msz, py, scale, xv, gx, dw, dyp, it.chunk);              \
+        break;
+        switch (p.l2 * 4 + p.l3) {
+            TFC_BWD_CASE(0, 0) TFC_BWD_CASE(0, 1) TFC_BWD_CASE(0, 2) TFC_BWD_CASE(0, 3)
+            TFC_BWD_CASE(1, 0) TFC_BWD_CASE(1, 1) TFC_BWD_CASE(1, 2) TFC_BWD_CASE(1, 3)
+            TFC_BWD_CASE(2, 0) TFC_BWD_CASE(2, 1) TFC_BWD_CASE(2, 2) TFC_BWD_CASE(2, 3)
+            TFC_BWD_CASE(3, 0) TFC_BWD_CASE(3, 1) TFC_BWD_CASE(3, 2) TFC_BWD_CASE(3, 3)
+            default: break;
+        }
+#undef TFC_BWD_CASE
+    }
+    if (active) {
+        float* o = dx + (size_t)node * d_in + it.x_off + u * D1;
+#pragma unroll
+        for (int m1 = 0; m1 < D1; ++m1) o[m1] = gx[m1];
+    }
+}
+
+template <bool NEED_DY>
+__global__ __launch_bounds__(256) void tfc_conv_bwd_kernel(
+    const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ gout,
+    const float* __restrict__ M, const float* __restrict__ cgd, const int* __restrict__ row_ptr,
+    const int* __restrict__ eid, const int* __restrict__ nbr, const PathDev* __restrict__ paths,
+    const BwdItem* __restrict__ items, const int* __restrict__ grp_paths, int n_items, long n_tasks,
+    int d_in, int d_out, int w_numel, int msz, int py, float scale, float* __restrict__ dx,
+    float* __restrict__ dw, float* __restrict__ dyp) {
+    const unsigned vb = tfc_xcd_remap(blockIdx.x, gridDim.x);
+    const int wave = tfc_uniform((int)(threadIdx.x >> 6));
+    const int lane = threadIdx.x & 63;
+    const long task = (long)vb * 4 + wave;
+    if (task >= n_tasks) return;
+    const int node = (int)(task / n_items);
+    const int item = (int)(task - (long)node * n_items);
+    const BwdItem it = items[item];
+    const int beg = tfc_uniform(row_ptr[node]);
+    const int end = tfc_uniform(row_ptr[node + 1]);
+    switch (it.l1) {
+        case 0:
+            bwd_item<0, NEED_DY>(x, w, gout, M, cgd, eid, nbr, paths, grp_paths, it, beg, end, node, lane,
+                                 d_in, d_out, w_numel, msz, py, scale, dx, dw, dyp);
+            break;
+        case 1:
+            bwd_item<1, NEED_DY>(x, w, gout, M, cgd, eid, nbr, paths, grp_paths, it, beg, end, node, lane,
+                                 d_in, d_out, w_numel, msz, py, scale, dx, dw, dyp);
+            break;
+        case 2:
+            bwd_item<2, NEED_DY>(x, w, gout, M, cgd, eid, nbr, paths, grp_paths, it, beg, end, node, lane,
+                                 d_in, d_out, w_numel, msz, py, scale, dx, dw, dyp);
+            break;
+        case 3:
+            bwd_item<3, NEED_DY>(x, w, gout, M, cgd, eid, nbr, paths, grp_paths, it, beg, end, node, lane,
+                                 d_in, d_out, w_numel, msz, py, scale, dx, dw, dyp);
+            break;
+        default: break;
+    }
+}
+
+// dy[e][j] = sum of the partial-dy columns that belong to edge-attribute column j
+__global__ __launch_bounds__(256) void tfc_dy_reduce_kernel(const float* __restrict__ dyp,
+                                                            const int* __restrict__ ylist_ptr,
+                                                            const int* __restrict__ ylist, long n_edges,
+                                                            int d_sh, int py, float* __restrict__ dy) {
+    const long total = n_edges * (long)d_sh;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (long)gridDim.x * blockDim.x) {
+        const long e = i / d_sh;
+        const int j = (int)(i - e * d_sh);
+        const float* r = dyp + e * (long)py;
+        float s = 0.f;
+        for (int t = ylist_ptr[j]; t < ylist_ptr[j + 1]; ++t) s += r[ylist[t]];
+        dy[i] = s;
+    }
+}
+
+// zero-fill of rows no item writes (input blocks read by no path)
+__global__ __launch_bounds__(256) void tfc_fill_kernel(float* __restrict__ p, long n, float v) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+        p[i] = v;
+}
+
+// ------------------------------------------------------------------------------------------
+// Host side
+// ------------------------------------------------------------------------------------------
+static inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
+
+extern "C" int tfc_conv_plan_create(const tfc_path* paths, int32_t n_paths, int32_t d_in, int32_t d_sh,
+                                    int32_t d_out, int32_t w_numel, tfc_conv_plan** plan_out) {
+    TFC_REQUIRE(paths && plan_out, TFC_EINVAL, "tfc_conv_plan_create: null argument");
+    TFC_REQUIRE(n_paths > 0 && n_paths <= 4096, TFC_EINVAL, "tfc_conv_plan_create: n_paths=%d", n_paths);
+    TFC_REQUIRE(d_in > 0 && d_sh > 0 && d_out > 0 && w_numel > 0, TFC_EINVAL,
+                "tfc_conv_plan_create: non-positive row size");
+    *plan_out = nullptr;
+
+    std::vector<PathDev> pd(n_paths);
+    std::map<std::tuple<int, int, int, int>, int> triple_index;  // (l1,l2,l3,y_off) -> index
+    std::vector<std::tuple<int, int, int, int>> triples;
+    std::vector<char> out_used(d_out, 0);
+    for (int i = 0; i < n_paths; ++i) {
+        const tfc_path& p = paths[i];
+        TFC_REQUIRE(p.l1 >= 0 && p.l2 >= 0 && p.l3 >= 0 && p.l1 <= TFC_LMAX && p.l2 <= TFC_LMAX &&
+                        p.l3 <= TFC_LMAX,
+                    TFC_EUNSUPPORTED, "path %d: l=(%d,%d,%d) outside 0..%d", i, p.l1, p.l2, p.l3, TFC_LMAX);
+        TFC_REQUIRE(std::abs(p.l1 - p.l2) <= p.l3 && p.l3 <= p.l1 + p.l2, TFC_EINVAL,
+                    "path %d: (%d,%d,%d) violates the triangle rule", i, p.l1, p.l2, p.l3);
+        TFC_REQUIRE(p.mul > 0, TFC_EINVAL, "path %d: mul=%d", i, p.mul);
+        TFC_REQUIRE(p.x_off >= 0 && p.x_off + p.mul * (2 * p.l1 + 1) <= d_in, TFC_EINVAL,
+                    "path %d: in1 block outside the node-feature row", i);
+        TFC_REQUIRE(p.y_off >= 0 && p.y_off + (2 * p.l2 + 1) <= d_sh, TFC_EINVAL,
+                    "path %d: in2 block outside the edge-attribute row", i);
+        TFC_REQUIRE(p.out_off >= 0 && p.out_off + p.mul * (2 * p.l3 + 1) <= d_out, TFC_EINVAL,
+                    "path %d: output block outside the output row", i);
+        TFC_REQUIRE(p.w_off >= 0 && p.w_off + p.mul <= w_numel, TFC_EINVAL,
+                    "path %d: weights outside the weight row", i);
+        for (int c = p.out_off; c < p.out_off + p.mul * (2 * p.l3 + 1); ++c) {
+            TFC_REQUIRE(!out_used[c], TFC_EUNSUPPORTED, "path %d shares its output block with another path",
+                        i);
+            out_used[c] = 1;
+        }
+        auto key = std::make_tuple(p.l1, p.l2, p.l3, p.y_off);
+        if (!triple_index.count(key)) {
+            triple_index[key] = (int)triples.size();
+            triples.push_back(key);
+        }
+        pd[i] = PathDev{p.l1, p.l2, p.l3, p.mul, p.x_off, p.y_off, p.out_off, p.w_off, 0, 0, 0, p.coeff};
+    }
+
+    // M-row layout + CG tables per triple
+    std::vector<int> t_moff(triples.size()), t_cgoff(triples.size());
+    std::vector<MEnt> ments;
+    std::vector<float> cgm, cgd;
+    std::vector<double> cg;
+    for (size_t t = 0; t < triples.size(); ++t) {
+        int l1, l2, l3, yo;
+        std::tie(l1, l2, l3, yo) = triples[t];
+        const int D1 = 2 * l1 + 1, D2 = 2 * l2 + 1, D3 = 2 * l3 + 1;
+        cg.assign((size_t)D1 * D2 * D3, 0.0);
+        int rc = tfc_real_cg(l1, l2, l3, cg.data());
+        if (rc != TFC_OK) return rc;
+        t_moff[t] = (int)ments.size();
+        t_cgoff[t] = (int)cgd.size();
+        for (double v : cg) cgd.push_back((float)v);
+        for (int m1 = 0; m1 < D1; ++m1)
+            for (int m3 = 0; m3 < D3; ++m3) {
+                MEnt me{(int)cgm.size(), yo, D2};
+                for (int m2 = 0; m2 < D2; ++m2) cgm.push_back((float)cg[((size_t)m1 * D2 + m2) * D3 + m3]);
+                ments.push_back(me);
+            }
+        while (ments.size() % 4) ments.push_back(MEnt{0, 0, 0});
+    }
+    const int msz = (int)ments.size();
+    if (cgm.empty()) cgm.push_back(0.f);
+
+    // forward items: (path, 64-channel chunk); partial-dy slots in the same order
+    std::vector<FwdItem> fwd_items;
+    int py = 0;
+    std::vector<std::vector<int>> ycols(d_sh);
+    for (int i = 0; i < n_paths; ++i) {
+        auto key = std::make_tuple(pd[i].l1, pd[i].l2, pd[i].l3, pd[i].y_off);
+        const int t = triple_index[key];
+        pd[i].m_off = t_moff[t];
+        pd[i].cg_off = t_cgoff[t];
+        pd[i].py_off = py;
+        const int chunks = (pd[i].mul + 63) / 64;
+        for (int c = 0; c < chunks; ++c) {
+            fwd_items.push_back(FwdItem{i, c});
+            for (int m2 = 0; m2 < 2 * pd[i].l2 + 1; ++m2) ycols[pd[i].y_off + m2].push_back(py + m2);
+            py += 2 * pd[i].l2 + 1;
+        }
+    }
+    // order forward items by in1 block so that waves sharing gathered lines are neighbours
+    std::stable_sort(fwd_items.begin(), fwd_items.end(), [&](const FwdItem& a, const FwdItem& b) {
+        return std::make_pair(pd[a.path].x_off, a.chunk) < std::make_pair(pd[b.path].x_off, b.chunk);
+    });
+
+    // backward items: (in1 block, chunk) with the list of paths reading the block
+    std::map<std::tuple<int, int, int>, std::vector<int>> groups;  // (x_off, l1, mul) -> paths
+    for (int i = 0; i < n_paths; ++i) groups[std::make_tuple(pd[i].x_off, pd[i].l1, pd[i].mul)].push_back(i);
+    std::vector<BwdItem> bwd_items;
+    std::vector<int> grp_paths;
+    for (auto& kv : groups) {
+        int xo, l1, mul;
+        std::tie(xo, l1, mul) = kv.first;
+        const int start = (int)grp_paths.size();
+        for (int pi : kv.second) grp_paths.push_back(pi);
+        for (int c = 0; c < (mul + 63) / 64; ++c)
+            bwd_items.push_back(BwdItem{start, (int)kv.second.size(), c, l1, xo, mul});
+    }
+    // in1 blocks must not partially overlap (same offset => same block)
+    {
+        std::vector<char> used(d_in, 0);
+        for (auto& kv : groups) {
+            int xo, l1, mul;
+            std::tie(xo, l1, mul) = kv.first;
+            for (int c = xo; c < xo + mul * (2 * l1 + 1); ++c) {
+                TFC_REQUIRE(!used[c], TFC_EUNSUPPORTED, "overlapping in1 blocks at column %d", c);
+                used[c] = 1;
+            }
+        }
+    }
+
+    std::vector<int> ylist_ptr(d_sh + 1, 0), ylist;
+    for (int j = 0; j < d_sh; ++j) {
+        ylist_ptr[j] = (int)ylist.size();
+        for (int c : ycols[j]) ylist.push_back(c);
+    }
+    ylist_ptr[d_sh] = (int)ylist.size();
+    if (ylist.empty()) ylist.push_back(0);
+
+    // one device blob for all tables
+    auto al = [](size_t v) { return (v + 255) / 256 * 256; };
+    size_t o_paths = 0;
+    size_t o_fwd = al(o_paths + pd.size() * sizeof(PathDev));
+    size_t o_bwd = al(o_fwd + fwd_items.size() * sizeof(FwdItem));
+    size_t o_grp = al(o_bwd + bwd_items.size() * sizeof(BwdItem));
+    size_t o_ment = al(o_grp + grp_paths.size() * sizeof(int));
+    size_t o_cgm = al(o_ment + ments.size() * sizeof(MEnt));
+    size_t o_cgd = al(o_cgm + cgm.size() * sizeof(float));
+    size_t o_ylp = al(o_cgd + cgd.size() * sizeof(float));
+    size_t o_yl = al(o_ylp + ylist_ptr.size() * sizeof(int));
+    size_t total = al(o_yl + ylist.size() * sizeof(int));
+    std::vector<char> host(total, 0);
+    std::memcpy(host.data() + o_paths, pd.data(), pd.size() * sizeof(PathDev));
+    std::memcpy(host.data() + o_fwd, fwd_items.data(), fwd_items.size() * sizeof(FwdItem));
+    std::memcpy(host.data() + o_bwd, bwd_items.data(), bwd_items.size() * sizeof(BwdItem));
+    std::memcpy(host.data() + o_grp, grp_paths.data(), grp_paths.size() * sizeof(int));
+    std::memcpy(host.data() + o_ment, ments.data(), ments.size() * sizeof(MEnt));
+    std::memcpy(host.data() + o_cgm, cgm.data(), cgm.size() * sizeof(float));
+    std::memcpy(host.data() + o_cgd, cgd.data(), cgd.size() * sizeof(float));
+    std::memcpy(host.data() + o_ylp, ylist_ptr.data(), ylist_ptr.size() * sizeof(int));
+    std::memcpy(host.data() + o_yl, ylist.data(), ylist.size() * sizeof(int));
+
+    tfc_conv_plan* pl = new (std::nothrow) tfc_conv_plan();
+    TFC_REQUIRE(pl, TFC_ENOMEM, "tfc_conv_plan_create: out of host memory");
+    hipError_t e = hipGetDevice(&pl->device);
+    if (e == hipSuccess) e = hipMalloc(&pl->blob, total);
+    if (e == hipSuccess) e = hipMemcpy(pl->blob, host.data(), total, hipMemcpyHostToDevice);
+    if (e != hipSuccess) {
+        if (pl->blob) (void)hipFree(pl->blob);
+        delete pl;
+        return tfc_set_error(e == hipErrorOutOfMemory ? TFC_ENOMEM : TFC_ELAUNCH,
+                             "tfc_conv_plan_create: device table upload failed: %s", hipGetErrorString(e));
+    }
+    char* b = (char*)pl->blob;
+    pl->n_paths = n_paths;
+    pl->d_in = d_in;
+    pl->d_sh = d_sh;
+    pl->d_out = d_out;
+    pl->w_numel = w_numel;
+    pl->msz = msz;
+    pl->py = py;
+    pl->n_fwd_items = (int)fwd_items.size();
+    pl->n_bwd_items = (int)bwd_items.size();
+    pl->paths = (PathDev*)(b + o_paths);
+    pl->fwd_items = (FwdItem*)(b + o_fwd);
+    pl->bwd_items = (BwdItem*)(b + o_bwd);
+    pl->grp_paths = (int*)(b + o_grp);
+    pl->ments = (MEnt*)(b + o_ment);
+    pl->cgm = (float*)(b + o_cgm);
+    pl->cgd = (float*)(b + o_cgd);
+    pl->ylist_ptr = (int*)(b + o_ylp);
+    pl->ylist = (int*)(b + o_yl);
+    *plan_out = pl;
+    return TFC_OK;
+}
+
+extern "C" int tfc_conv_plan_destroy(tfc_conv_plan* plan) {
+    if (!plan) return TFC_OK;
+    if (plan->blob) (void)hipFree(plan->blob);
+    delete plan;
+    return TFC_OK;
+}
+
+extern "C" int64_t tfc_conv_workspace_floats(const tfc_conv_plan* plan, int64_t n_edges, int need_dy) {
+    if (!plan || n_edges < 0) return -1;
+    int64_t f = n_edges * (int64_t)plan->msz;
+    if (need_dy) f += n_edges * (int64_t)plan->py;
+    return f > 0 ? f : 1;
+}
+
+static inline int grid_for(long n, int per_block, int cap = 8192) {
+    long g = (n + per_block - 1) / per_block;
+    if (g < 1) g = 1;
+    if (g > cap) g = cap;
+    return (int)g;
+}
+
+extern "C" int tfc_conv_fwd(const tfc_conv_plan* pl, const float* x, const float* y, const float* w,
+                            const int32_t* row_ptr, const int32_t* eid, const int32_t* nbr, int64_t n_nodes,
+                            int64_t n_edges, float scale, float* out, float* workspace, tfc_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    TFC_REQUIRE(pl, TFC_EINVAL, "tfc_conv_fwd: null plan");
+    TFC_REQUIRE(n_nodes >= 0 && n_edges >= 0, TFC_EINVAL, "tfc_conv_fwd: negative size");
+    TFC_REQUIRE(n_nodes < (1LL << 31) && n_edges < (1LL << 31), TFC_EUNSUPPORTED,
+                "tfc_conv_fwd: more than 2^31 nodes or edges");
+    if (n_nodes == 0) return TFC_OK;
+    TFC_REQUIRE(x && out && row_ptr, TFC_EINVAL, "tfc_conv_fwd: null tensor");
+    TFC_REQUIRE(n_edges == 0 || (y && w && eid && nbr && workspace), TFC_EINVAL, "tfc_conv_fwd: null tensor");
+    float* M = workspace;
+    if (n_edges > 0) {
+        tfc_m_prepass_kernel<<<grid_for(n_edges * (long)pl->msz, 256), 256, 0, stream>>>(
+            y, eid, pl->ments, pl->cgm, (long)n_edges, pl->msz, pl->d_sh, M);
+        TFC_LAUNCH_CHECK("tfc_m_prepass_kernel");
+    }
+    const long n_tasks = (long)n_nodes * pl->n_fwd_items;
+    const long n_blocks = (n_tasks + 3) / 4;
+    TFC_REQUIRE(n_blocks < (1LL << 31), TFC_EUNSUPPORTED, "tfc_conv_fwd: grid too large");
+    tfc_conv_fwd_kernel<<<(unsigned)n_blocks, 256, 0, stream>>>(
+        x, w, M, row_ptr, eid, nbr, pl->paths, pl->fwd_items, pl->n_fwd_items, n_tasks, pl->d_in, pl->d_out,
+        pl->w_numel, pl->msz, scale, out);
+    TFC_LAUNCH_CHECK("tfc_conv_fwd_kernel");
+    return TFC_OK;
+}
+
+extern "C" int tfc_conv_bwd(const tfc_conv_plan* pl, const float* x, const float* y, const float* w,
+                            const float* gout, const int32_t* row_ptr, const int32_t* eid, const int32_t* nbr,
+                            int64_t n_nodes, int64_t n_edges, float scale, float* dx, float* dw, float* dy,
+                            float* workspace, tfc_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    TFC_REQUIRE(pl, TFC_EINVAL, "tfc_conv_bwd: null plan");
+    TFC_REQUIRE(n_nodes >= 0 && n_edges >= 0, TFC_EINVAL, "tfc_conv_bwd: negative size");
+    TFC_REQUIRE(n_nodes < (1LL << 31) && n_edges < (1LL << 31), TFC_EUNSUPPORTED,
+                "tfc_conv_bwd: more than 2^31 nodes or edges");
+    if (n_nodes == 0) return TFC_OK;
+    TFC_REQUIRE(x && gout && dx && row_ptr, TFC_EINVAL, "tfc_conv_bwd: null tensor");
+    TFC_REQUIRE(n_edges == 0 || (y && w && dw && eid && nbr && workspace), TFC_EINVAL,
+                "tfc_conv_bwd: null tensor");
+    float* M = workspace;
+    float* dyp = workspace + (size_t)n_edges * pl->msz;
+    // columns of dx / dw that no path touches must still be defined
+    tfc_fill_kernel<<<grid_for((long)n_nodes * pl->d_in, 256, 2048), 256, 0, stream>>>(
+        dx, (long)n_nodes * pl->d_in, 0.f);
+    TFC_LAUNCH_CHECK("tfc_fill_kernel");
+    if (n_edges > 0) {
+        tfc_m_prepass_kernel<<<grid_for(n_edges * (long)pl->msz, 256), 256, 0, stream>>>(
+            y, eid, pl->ments, pl->cgm, (long)n_edges, pl->msz, pl->d_sh, M);
+        TFC_LAUNCH_CHECK("tfc_m_prepass_kernel");
+    }
+    const long n_tasks = (long)n_nodes * pl->n_bwd_items;
+    const long n_blocks = (n_tasks + 3) / 4;
+    TFC_REQUIRE(n_blocks < (1LL << 31), TFC_EUNSUPPORTED, "tfc_conv_bwd: grid too large");
+    if (dy) {
+        tfc_conv_bwd_kernel<true><<<(unsigned)n_blocks, 256, 0, stream>>>(
+            x, w, gout, M, pl->cgd, row_ptr, eid, nbr, pl->paths, pl->bwd_items, pl->grp_paths,
+            pl->n_bwd_items, n_tasks, pl->d_in, pl->d_out, pl->w_numel, pl->msz, pl->py, scale, dx, dw, dyp);
+        TFC_LAUNCH_CHECK("tfc_conv_bwd_kernel<dy>");
+        if (n_edges > 0) {
+            tfc_dy_reduce_kernel<<<grid_for(n_edges * (long)pl->d_sh, 256, 2048), 256, 0, stream>>>(
+                dyp, pl->ylist_ptr, pl->ylist, (long)n_edges, pl->d_sh, pl->py, dy);
+            TFC_LAUNCH_CHECK("tfc_dy_reduce_kernel");
+        }
+    } else {
+        tfc_conv_bwd_kernel<false><<<(unsigned)n_blocks, 256, 0, stream>>>(
+            x, w, gout, M, pl->cgd, row_ptr, eid, nbr, pl->paths, pl->bwd_items, pl->grp_paths,
+            pl->n_bwd_items, n_tasks, pl->d_in, pl->d_out, pl->w_numel, pl->msz, pl->py, scale, dx, dw,
+            nullptr);
+        TFC_LAUNCH_CHECK("tfc_conv_bwd_kernel");
+    }
+    return TFC_OK;
+}

@@ -1,0 +1,158 @@
+// Gate non-linearity: out = [ act(scalars) | act(gates) * gated ].
+// Replaces e3nn.nn.Gate as built at eigenn/nn/utils.py:134-140 and applied at
+// eigenn/nn/point_conv.py:339 (Activation with normalize2mom constants, then an
+// ElementwiseTensorProduct that is a plain multiply), and its autograd backward.
+// Elementwise and HBM-bound: one thread per output (forward) / input (backward) column.
+#include "tfc_common.h"
+
+#include <algorithm>
+
+namespace {
+
+constexpr int MAX_SEGS = 32;
+
+struct GateSegs {
+    tfc_gate_seg s[MAX_SEGS];
+    int n;
+};
+
+__device__ __forceinline__ float act_eval(int act, float x) {
+    switch (act) {
+        case TFC_ACT_SSP: return (x > 20.f ? x : log1pf(expf(x))) - 0.69314718055994530942f;
+        case TFC_ACT_SILU: return x / (1.f + expf(-x));
+        case TFC_ACT_TANH: return tanhf(x);
+        case TFC_ACT_ABS: return fabsf(x);
+        case TFC_ACT_SIGMOID: return 1.f / (1.f + expf(-x));
+        default: return x;
+    }
+}
+
+__device__ __forceinline__ float act_grad(int act, float x) {
+    switch (act) {
+        case TFC_ACT_SSP: return x > 20.f ? 1.f : 1.f / (1.f + expf(-x));
+        case TFC_ACT_SILU: {
+            const float s = 1.f / (1.f + expf(-x));
+            return s * (1.f + x * (1.f - s));
+        }
+        case TFC_ACT_TANH: {
+            const float t = tanhf(x);
+            return 1.f - t * t;
+        }
+        case TFC_ACT_ABS: return x > 0.f ? 1.f : (x < 0.f ? -1.f : 0.f);
+        case TFC_ACT_SIGMOID: {
+            const float s = 1.f / (1.f + expf(-x));
+            return s * (1.f - s);
+        }
+        default: return 1.f;
+    }
+}
+
+__global__ __launch_bounds__(256) void tfc_gate_fwd_kernel(const GateSegs g, const float* __restrict__ x,
+                                                           long n_rows, int d_in, int d_out,
+                                                           float* __restrict__ out) {
+    const long total = n_rows * (long)d_out;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (long)gridDim.x * blockDim.x) {
+        const long r = i / d_out;
+        const int c = (int)(i - r * d_out);
+        const float* xr = x + r * (long)d_in;
+        float v = 0.f;
+        for (int s = 0; s < g.n; ++s) {
+            const tfc_gate_seg sg = g.s[s];
+            const int idx = c - sg.out_off;
+            if (idx < 0 || idx >= sg.count * sg.dim) continue;
+            if (sg.gate_off < 0) {
+                v = sg.cst * act_eval(sg.act, xr[sg.in_off + idx]);
+            } else {
+                const int u = idx / sg.dim;
+                v = sg.cst * act_eval(sg.act, xr[sg.gate_off + u]) * xr[sg.in_off + idx];
+            }
+            break;
+        }
+        out[i] = v;
+    }
+}
+
+__global__ __launch_bounds__(256) void tfc_gate_bwd_kernel(const GateSegs g, const float* __restrict__ x,
+                                                           const float* __restrict__ gout, long n_rows, int d_in,
+                                                           int d_out, float* __restrict__ dx) {
+    const long total = n_rows * (long)d_in;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (long)gridDim.x * blockDim.x) {
+        const long r = i / d_in;
+        const int c = (int)(i - r * d_in);
+        const float* xr = x + r * (long)d_in;
+        const float* gr = gout + r * (long)d_out;
+        float v = 0.f;
+        for (int s = 0; s < g.n; ++s) {
+            const tfc_gate_seg sg = g.s[s];
+            const int idx = c - sg.in_off;
+            if (idx >= 0 && idx < sg.count * sg.dim) {
+                if (sg.gate_off < 0) {
+                    v = gr[sg.out_off + idx] * sg.cst * act_grad(sg.act, xr[c]);
+                } else {
+                    const int u = idx / sg.dim;
+                    v = gr[sg.out_off + idx] * sg.cst * act_eval(sg.act, xr[sg.gate_off + u]);
+                }
+                break;
+            }
+            const int gu = c - sg.gate_off;
+            if (sg.gate_off >= 0 && gu >= 0 && gu < sg.count) {
+                float dot = 0.f;
+                for (int m = 0; m < sg.dim; ++m)
+                    dot = fmaf(gr[sg.out_off + gu * sg.dim + m], xr[sg.in_off + gu * sg.dim + m], dot);
+                v = dot * sg.cst * act_grad(sg.act, xr[c]);
+                break;
+            }
+        }
+        dx[i] = v;
+    }
+}
+
+int pack_segs(const tfc_gate_seg* segs, int32_t n_segs, int32_t d_in, int32_t d_out, GateSegs* out) {
+    TFC_REQUIRE(segs && n_segs > 0 && n_segs <= MAX_SEGS, TFC_EINVAL, "tfc_gate: n_segs=%d outside 1..%d", n_segs,
+                MAX_SEGS);
+    for (int i = 0; i < n_segs; ++i) {
+        const tfc_gate_seg& s = segs[i];
+        TFC_REQUIRE(s.count >= 0 && s.dim >= 1 && s.in_off >= 0 && s.out_off >= 0 &&
+                        s.in_off + s.count * s.dim <= d_in && s.out_off + s.count * s.dim <= d_out &&
+                        (s.gate_off < 0 || s.gate_off + s.count <= d_in) && (s.gate_off >= 0 || s.dim == 1) &&
+                        s.act >= TFC_ACT_IDENTITY && s.act <= TFC_ACT_SIGMOID,
+                    TFC_EINVAL, "tfc_gate: segment %d is inconsistent", i);
+        out->s[i] = s;
+    }
+    out->n = n_segs;
+    return TFC_OK;
+}
+
+}  // namespace
+
+extern "C" int tfc_gate_fwd(const tfc_gate_seg* segs, int32_t n_segs, const float* x, int64_t n_rows, int32_t d_in,
+                            int32_t d_out, float* out, tfc_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    TFC_REQUIRE(n_rows >= 0 && d_in > 0 && d_out > 0, TFC_EINVAL, "tfc_gate_fwd: bad size");
+    GateSegs g;
+    int rc = pack_segs(segs, n_segs, d_in, d_out, &g);
+    if (rc) return rc;
+    if (n_rows == 0) return TFC_OK;
+    TFC_REQUIRE(x && out, TFC_EINVAL, "tfc_gate_fwd: null tensor");
+    const int grid = (int)std::min<long>((n_rows * (long)d_out + 255) / 256, 8192);
+    tfc_gate_fwd_kernel<<<grid, 256, 0, stream>>>(g, x, (long)n_rows, d_in, d_out, out);
+    TFC_LAUNCH_CHECK("tfc_gate_fwd_kernel");
+    return TFC_OK;
+}
+
+extern "C" int tfc_gate_bwd(const tfc_gate_seg* segs, int32_t n_segs, const float* x, const float* gout,
+                            int64_t n_rows, int32_t d_in, int32_t d_out, float* dx, tfc_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    TFC_REQUIRE(n_rows >= 0 && d_in > 0 && d_out > 0, TFC_EINVAL, "tfc_gate_bwd: bad size");
+    GateSegs g;
+    int rc = pack_segs(segs, n_segs, d_in, d_out, &g);
+    if (rc) return rc;
+    if (n_rows == 0) return TFC_OK;
+    TFC_REQUIRE(x && gout && dx, TFC_EINVAL, "tfc_gate_bwd: null tensor");
+    const int grid = (int)std::min<long>((n_rows * (long)d_in + 255) / 256, 8192);
+    tfc_gate_bwd_kernel<<<grid, 256, 0, stream>>>(g, x, gout, (long)n_rows, d_in, d_out, dx);
+    TFC_LAUNCH_CHECK("tfc_gate_bwd_kernel");
+    return TFC_OK;
+}

@@ -1,0 +1,24 @@
+"""Keys of the data dict passed between layers (the reference's `DataKey`,
+eigenn/data/_key.py:14-47).  Same strings, so dicts are interchangeable."""
+from typing import Dict
+
+import torch
+
+Type = Dict[str, torch.Tensor]
+
+POSITIONS = "pos"
+NODE_ATTRS = "node_attrs"
+NODE_FEATURES = "node_features"
+EDGE_INDEX = "edge_index"
+EDGE_CELL_SHIFT = "edge_cell_shift"
+EDGE_VECTORS = "edge_vectors"
+EDGE_LENGTH = "edge_lengths"
+EDGE_ATTRS = "edge_attrs"
+EDGE_EMBEDDING = "edge_embedding"
+EDGE_MESSAGE = "edge_message"
+CELL = "cell"
+ATOMIC_NUMBERS = "atomic_numbers"
+SPECIES_INDEX = "species_index"
+PER_ATOM_ENERGY = "atomic_energy"
+TOTAL_ENERGY = "total_energy"
+BATCH = "batch"

@@ -1,0 +1,11 @@
+from .edge_encoding import (  # noqa: F401
+    BesselBasis,
+    PolynomialCutoff,
+    RadialBasisEdgeEncoding,
+    ShiftedSoftPlus,
+    SphericalHarmonicEdgeAttrs,
+    with_batch,
+    with_edge_vectors,
+)
+from .point_conv import PointConv, PointConvMessage, PointConvMessagePassing, PointConvUpdate  # noqa: F401
+from .utils import ActivationLayer, UVUTensorProduct, scatter_add, tp_path_exists  # noqa: F401

@@ -1,0 +1,292 @@
+"""The e3nn building blocks the layer is composed of, with e3nn's parameter layout and
+normalisation but computed by the libtfc kernels.
+
+The reference constructs these from e3nn (o3.Linear, o3.FullyConnectedTensorProduct,
+o3.TensorProduct, nn.FullyConnectedNet, nn.Gate; call sites eigenn/nn/point_conv.py:56-61,
+130-135,160-162 and eigenn/nn/utils.py:134-140,231-252).  Parameter names, shapes and
+flattening order are e3nn's, so reference state_dicts load key for key.  Each module only
+derives a host-side *spec* (offsets, multiplicities, normalisation constants); all
+arithmetic happens in matten_amd.ops.
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, List, Optional, Sequence
+
+import torch
+
+from .. import ops
+from .._lib import ACT
+from ..irreps import Irrep, Irreps
+
+# e3nn.math.normalize2mom constants: cst = E[act(z)^2]^(-1/2) over z = torch.randn(1_000_000,
+# generator=manual_seed(0), dtype=float64) - a Monte-Carlo value, NOT the analytic one
+# (regenerate with tools/normalize2mom_constants.py).
+NORMALIZE2MOM = {
+    "ssp": 1.878204668541552,
+    "silu": 1.6791767923989418,
+    "tanh": 1.5937334472592692,
+    "abs": 1.001110600838467,
+    "sigmoid": 1.8467055342154763,
+    "identity": 1.0,
+}
+
+# parity behaviour of each activation (e3nn.nn.Activation): even functions map 0o -> 0e,
+# odd functions keep 0o, anything else cannot act on an odd scalar.
+_ACT_SYMMETRY = {"abs": "even", "tanh": "odd", "identity": "odd"}
+
+
+def _n2m(name: str) -> float:
+    c = NORMALIZE2MOM[name]
+    return 1.0 if abs(c - 1.0) < 1e-4 else c
+
+
+class Linear(torch.nn.Module):
+    """o3.Linear(irreps_in, irreps_out): one weight block [mul_in, mul_out] per pair of equal
+    irreps (loop order in, out), flattened into a 1-D `weight`; path weight
+    1/sqrt(sum of mul_in reaching the output block); no bias."""
+
+    def __init__(self, irreps_in, irreps_out):
+        super().__init__()
+        self.irreps_in = Irreps(irreps_in)
+        self.irreps_out = Irreps(irreps_out)
+        in_offs, out_offs = self.irreps_in.offsets(), self.irreps_out.offsets()
+        pairs = [
+            (a, b)
+            for a, mi in enumerate(self.irreps_in)
+            for b, mo in enumerate(self.irreps_out)
+            if mi.ir == mo.ir
+        ]
+        ins, w_off = [], 0
+        for a, b in pairs:
+            mi, mo = self.irreps_in[a], self.irreps_out[b]
+            fan = sum(self.irreps_in[a2].mul for a2, b2 in pairs if b2 == b)
+            if mi.mul > 0 and mo.mul > 0:
+                ins.append((in_offs[a], mi.mul, out_offs[b], mo.mul, mi.ir.dim, w_off, fan**-0.5))
+            w_off += mi.mul * mo.mul
+        self.weight_numel = w_off
+        self.weight = torch.nn.Parameter(torch.randn(w_off))
+        covered_out = {b for _, b in pairs}
+        covered_in = {a for a, _ in pairs}
+        self.spec = ops.LinearSpec(
+            d_in=self.irreps_in.dim,
+            d_out=self.irreps_out.dim,
+            weight_numel=w_off,
+            instructions=tuple(ins),
+            out_covered=all(b in covered_out or self.irreps_out[b].dim == 0 for b in range(len(self.irreps_out))),
+            in_covered=all(a in covered_in or self.irreps_in[a].dim == 0 for a in range(len(self.irreps_in))),
+        )
+
+    def forward(self, x):
+        return ops.linear(x, self.weight, self.spec)
+
+    def extra_repr(self):
+        return f"{self.irreps_in} -> {self.irreps_out} | {self.weight_numel} weights"
+
+
+class FullyConnectedTensorProduct(torch.nn.Module):
+    """o3.FullyConnectedTensorProduct(in1, in2, out) with internal shared weights: 'uvw'
+    instructions for every (i1, i2, io) with ir_out in ir1 x ir2 (loop order i1, i2, io),
+    weight blocks [mul1, mul2, mul_out] flattened into one `weight`.
+
+    The kernels cover the case the layer uses - a scalar (l = 0) second input, i.e. the
+    species-embedding node attributes (eigenn/nn/point_conv.py:159-164).  Other second inputs
+    construct (as in the reference's tests/nn/test_convolution.py) but raise at call time."""
+
+    def __init__(self, irreps_in1, irreps_in2, irreps_out):
+        super().__init__()
+        self.irreps_in1 = Irreps(irreps_in1).simplify()
+        self.irreps_in2 = Irreps(irreps_in2).simplify()
+        self.irreps_out = Irreps(irreps_out).simplify()
+        o1, o2, oo = self.irreps_in1.offsets(), self.irreps_in2.offsets(), self.irreps_out.offsets()
+        triples = [
+            (a, b, c)
+            for a, m1 in enumerate(self.irreps_in1)
+            for b, m2 in enumerate(self.irreps_in2)
+            for c, mo in enumerate(self.irreps_out)
+            if mo.ir in m1.ir * m2.ir
+        ]
+        ins, w_off = [], 0
+        self._unsupported = None
+        for a, b, c in triples:
+            m1, m2, mo = self.irreps_in1[a], self.irreps_in2[b], self.irreps_out[c]
+            fan = sum(self.irreps_in1[a2].mul * self.irreps_in2[b2].mul for a2, b2, c2 in triples if c2 == c)
+            alpha = mo.ir.dim / fan if fan > 0 else 0.0
+            if m2.ir.l != 0:
+                self._unsupported = f"second input {self.irreps_in2} is not scalar"
+            elif m1.mul * m2.mul * mo.mul > 0:
+                # C(l,0,l)[i,0,k] = delta_ik / sqrt(2l+1)
+                coeff = math.sqrt(alpha) / math.sqrt(mo.ir.dim)
+                ins.append((o1[a], m1.mul, o2[b], m2.mul, oo[c], mo.mul, mo.ir.dim, w_off, coeff))
+            w_off += m1.mul * m2.mul * mo.mul
+        self.weight_numel = w_off
+        self.weight = torch.nn.Parameter(torch.randn(w_off))
+        cov = lambda irreps, idx: all(i in idx or irreps[i].dim == 0 for i in range(len(irreps)))
+        self.spec = ops.FctpSpec(
+            d_x=self.irreps_in1.dim,
+            d_a=self.irreps_in2.dim,
+            d_out=self.irreps_out.dim,
+            weight_numel=w_off,
+            instructions=tuple(ins),
+            out_covered=cov(self.irreps_out, {c for _, _, c in triples}),
+            x_covered=cov(self.irreps_in1, {a for a, _, _ in triples}),
+            a_covered=cov(self.irreps_in2, {b for _, b, _ in triples}),
+        )
+
+    def forward(self, x, a, base: Optional[torch.Tensor] = None):
+        if self._unsupported:
+            raise NotImplementedError(f"matten_amd FullyConnectedTensorProduct: {self._unsupported}")
+        return ops.fctp(x, a, self.weight, self.spec, base)
+
+    def extra_repr(self):
+        return f"{self.irreps_in1} x {self.irreps_in2} -> {self.irreps_out} | {self.weight_numel} weights"
+
+
+class _FcLayer(torch.nn.Module):
+    def __init__(self, h_in: int, h_out: int):
+        super().__init__()
+        self.weight = torch.nn.Parameter(torch.randn(h_in, h_out))
+
+
+class FullyConnectedNet(torch.nn.Module):
+    """e3nn.nn.FullyConnectedNet(hs, act): layers `layer{i}.weight` [h_in, h_out] ~ randn, no
+    bias; hidden layers x <- cst*act(x @ W / sqrt(h_in)), last layer x <- x @ W / sqrt(h_in)."""
+
+    def __init__(self, hs: Sequence[int], act: str = "ssp"):
+        super().__init__()
+        self.hs = [int(h) for h in hs]
+        if act != "ssp":
+            raise NotImplementedError("matten_amd FullyConnectedNet: only the shifted-softplus activation is built")
+        self.act = act
+        self.act_cst = _n2m(act)
+        for i, (a, b) in enumerate(zip(self.hs, self.hs[1:])):
+            setattr(self, f"layer{i}", _FcLayer(a, b))
+
+    def forward(self, x):
+        ws = [getattr(self, f"layer{i}").weight for i in range(len(self.hs) - 1)]
+        return ops.radial_mlp(x, ws, self.act_cst)
+
+    def extra_repr(self):
+        return f"{self.hs} act={self.act}"
+
+
+class Gate(torch.nn.Module):
+    """e3nn.nn.Gate(irreps_scalars, act_scalars, irreps_gates, act_gates, irreps_gated) with the
+    activations given by name.  Input [scalars | gates | gated] (irreps_in is that sum,
+    simplified), output [act(scalars) | act(gates) * gated]."""
+
+    def __init__(self, irreps_scalars, act_scalars: Sequence[str], irreps_gates, act_gates: Sequence[str], irreps_gated):
+        super().__init__()
+        self.irreps_scalars = Irreps(irreps_scalars)
+        self.irreps_gates = Irreps(irreps_gates)
+        self.irreps_gated = Irreps(irreps_gated)
+        if len(self.irreps_gates) > 0 and self.irreps_gates.lmax > 0:
+            raise ValueError(f"Gate scalars must be scalars, instead got irreps_gates = {self.irreps_gates}")
+        if len(self.irreps_scalars) > 0 and self.irreps_scalars.lmax > 0:
+            raise ValueError(f"Scalars must be scalars, instead got irreps_scalars = {self.irreps_scalars}")
+        if self.irreps_gates.num_irreps != self.irreps_gated.num_irreps:
+            raise ValueError(
+                f"There are {self.irreps_gated.num_irreps} irreps in irreps_gated, but a different number "
+                f"({self.irreps_gates.num_irreps}) of gate scalars in irreps_gates"
+            )
+        if len(act_scalars) != len(self.irreps_scalars) or len(act_gates) != len(self.irreps_gates):
+            raise ValueError("Gate: one activation per irreps block is required")
+        self.irreps_in = (self.irreps_scalars + self.irreps_gates + self.irreps_gated).simplify()
+
+        def out_parity(act, p_in):
+            if p_in == 1:
+                return 1
+            sym = _ACT_SYMMETRY.get(act)
+            if sym == "even":
+                return 1
+            if sym == "odd":
+                return -1
+            raise ValueError(f"activation `{act}` cannot act on an odd scalar: it is neither even nor odd")
+
+        segs = []
+        out_irreps: List = []
+        in_off = out_off = 0
+        for (mul, ir), act in zip(self.irreps_scalars, act_scalars):
+            segs.append((in_off, out_off, mul, 1, -1, ACT[act], _n2m(act)))
+            out_irreps.append((mul, Irrep(0, out_parity(act, ir.p))))
+            in_off += mul
+            out_off += mul
+        # one (activation, parity) per gate channel, in order
+        gate_info = []
+        g_off = in_off
+        for (mul, ir), act in zip(self.irreps_gates, act_gates):
+            p_out = out_parity(act, ir.p)
+            gate_info += [(act, p_out)] * mul
+        in_off += self.irreps_gates.dim
+        u = 0
+        for mul, ir in self.irreps_gated.simplify():
+            start = 0
+            while start < mul:  # split where the gate's activation / parity changes
+                act, p = gate_info[u + start]
+                end = start
+                while end < mul and gate_info[u + end] == (act, p):
+                    end += 1
+                cnt = end - start
+                segs.append((in_off + start * ir.dim, out_off + start * ir.dim, cnt, ir.dim, g_off + u + start, ACT[act], _n2m(act)))
+                out_irreps.append((cnt, Irrep(ir.l, ir.p * p)))
+                start = end
+            in_off += mul * ir.dim
+            out_off += mul * ir.dim
+            u += mul
+        self.irreps_out = Irreps(out_irreps)
+        self.spec = ops.GateSpec(d_in=self.irreps_in.dim, d_out=self.irreps_out.dim, segs=tuple(segs))
+
+    def forward(self, x):
+        return ops.gate(x, self.spec)
+
+    def extra_repr(self):
+        return f"{self.irreps_in} -> {self.irreps_out}"
+
+
+class UVUTensorProductCore(torch.nn.Module):
+    """o3.TensorProduct(in1, in2, mid, instructions 'uvu', shared_weights=False,
+    internal_weights=False) fused with the gather of in1 rows and the per-node sum.
+
+    `instructions` = [(i_in1, i_in2, i_out)] in weight-slot order (eigenn/nn/utils.py:205-229).
+    Normalisation: irrep_normalization='component', path_normalization='element' =>
+    coefficient sqrt((2 l3 + 1) / sum of mul_in2 over the instructions sharing the output)."""
+
+    def __init__(self, irreps_in1, irreps_in2, irreps_out, instructions):
+        super().__init__()
+        self.irreps_in1 = Irreps(irreps_in1)
+        self.irreps_in2 = Irreps(irreps_in2)
+        self.irreps_out = Irreps(irreps_out)
+        self.instructions = [tuple(i[:3]) for i in instructions]
+        o1, o2, oo = self.irreps_in1.offsets(), self.irreps_in2.offsets(), self.irreps_out.offsets()
+        paths, w_off = [], 0
+        self._unsupported = None
+        for i1, i2, io in self.instructions:
+            m1, m2, mo = self.irreps_in1[i1], self.irreps_in2[i2], self.irreps_out[io]
+            if mo.ir not in m1.ir * m2.ir:
+                raise ValueError(f"{m1.ir} x {m2.ir} does not contain {mo.ir}")
+            if m1.mul != mo.mul:
+                raise ValueError("'uvu' needs mul_in1 == mul_out")
+            fan = sum(self.irreps_in2[j2].mul for _, j2, jo in self.instructions if jo == io)
+            if m2.mul != 1:
+                self._unsupported = f"edge attributes {self.irreps_in2} have a block of multiplicity {m2.mul} != 1"
+            if max(m1.ir.l, m2.ir.l, mo.ir.l) > 3:
+                self._unsupported = "l > 3"
+            paths.append(
+                dict(l1=m1.ir.l, l2=m2.ir.l, l3=mo.ir.l, mul=m1.mul, x_off=o1[i1], y_off=o2[i2], out_off=oo[io],
+                     w_off=w_off, coeff=math.sqrt(mo.ir.dim / fan))
+            )
+            w_off += m1.mul * m2.mul
+        self.weight_numel = w_off
+        self.plan = (
+            ops.ConvPlan([p for p in paths if p["mul"] > 0], self.irreps_in1.dim, self.irreps_in2.dim, self.irreps_out.dim, w_off)
+            if self._unsupported is None
+            else None
+        )
+
+    def forward(self, x, y, weight, ordering: ops.EdgeOrdering, scale: float = 1.0, per_edge: bool = False):
+        if self._unsupported:
+            raise NotImplementedError(f"matten_amd uvu tensor product: {self._unsupported}")
+        return ops.conv(x, y, weight, self.plan, ordering, scale, per_edge)
+
+    def extra_repr(self):
+        return f"{self.irreps_in1} x {self.irreps_in2} -> {self.irreps_out} | {len(self.instructions)} paths, {self.weight_numel} weights/edge"

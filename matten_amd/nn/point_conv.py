@@ -1,0 +1,241 @@
+"""The tensor-field convolution message-passing layer (eigenn/nn/point_conv.py), same
+classes, constructor arguments, irreps bookkeeping and parameter names, computed by the
+libtfc kernels.
+
+Fusion boundary.  In the reference, `PointConvMessage` materialises EDGE_MESSAGE [E, D_mid]
+and `PointConvUpdate` scatter-adds it.  Here, when the update function is the stock
+`PointConvUpdate` (always, in the two target models), the message function runs the fused
+kernel (sender gather + 'uvu' product + per-receiver sum + 1/sqrt(avg_num_neighbors)) and
+hands the [N, D_mid] node sums to the update function; the per-edge tensor is never
+written.  Nothing downstream reads EDGE_MESSAGE, but its irreps are still
+published in `irreps_out` so chained irreps dicts equal the reference's.  With
+`fuse_aggregation=False` (or a custom update class) the per-edge tensor is produced and
+summed afterwards, as in the reference.
+"""
+from __future__ import annotations
+
+from typing import Dict, Optional
+
+import torch
+
+from .. import keys as DataKey
+from .. import ops
+from ..irreps import Irreps
+from ..module_irreps import ModuleIrreps
+from .e3 import FullyConnectedTensorProduct, Linear
+from .utils import ActivationLayer, UVUTensorProduct, scatter_add
+
+__all__ = ["PointConvMessage", "PointConvUpdate", "PointConvMessagePassing", "PointConv", "compile_mode"]
+
+_NODE_MESSAGE = "_tfc_node_message"  # private hand-off: [N, D_mid] sums, already scaled
+
+
+def compile_mode(mode: str):
+    """Stand-in for e3nn.util.jit.compile_mode (a marker decorator, eigenn/nn/point_conv.py:197)."""
+
+    def deco(cls):
+        cls._e3nn_compile_mode = mode
+        return cls
+
+    return deco
+
+
+class PointConvMessage(ModuleIrreps, torch.nn.Module):
+    """eigenn/nn/point_conv.py:11-87"""
+
+    REQUIRED_KEYS_IRREPS_IN = [DataKey.NODE_FEATURES, DataKey.EDGE_EMBEDDING, DataKey.EDGE_ATTRS, DataKey.EDGE_INDEX]
+    REQUIRED_TYPE_IRREPS_IN = {DataKey.EDGE_EMBEDDING: "0e"}
+
+    def __init__(self, irreps_in: Dict[str, Irreps], irreps_out: Dict[str, Irreps], *, fc_num_hidden_layers: int = 1, fc_hidden_size: int = 8):
+        super().__init__()
+        self.init_irreps(irreps_in, irreps_out)
+        node_in = self.irreps_in[DataKey.NODE_FEATURES]
+        node_out = self.irreps_out[DataKey.NODE_FEATURES]
+        self.linear_1 = Linear(node_in, node_in)
+        self.tp = UVUTensorProduct(
+            node_in,
+            self.irreps_in[DataKey.EDGE_ATTRS],
+            node_out,
+            mlp_input_size=self.irreps_in[DataKey.EDGE_EMBEDDING].dim,
+            mlp_hidden_size=fc_hidden_size,
+            mlp_num_hidden_layers=fc_num_hidden_layers,
+        )
+        self.irreps_out[DataKey.EDGE_MESSAGE] = self.tp.irreps_out
+        # set by PointConvMessagePassing when the update function can take node sums
+        self.fuse_aggregation = False
+        self.aggregation_scale = 1.0
+
+    def forward(self, data: DataKey.Type) -> DataKey.Type:
+        x = self.linear_1(data[DataKey.NODE_FEATURES])
+        ordering = ops.edge_ordering(data[DataKey.EDGE_INDEX], x.shape[0])
+        if self.fuse_aggregation:
+            data[_NODE_MESSAGE] = self.tp(
+                x, data[DataKey.EDGE_ATTRS], data[DataKey.EDGE_EMBEDDING], ordering=ordering, scale=self.aggregation_scale
+            )
+            data.pop(DataKey.EDGE_MESSAGE, None)
+        else:
+            w = self.tp.weight_nn(data[DataKey.EDGE_EMBEDDING]) if self.tp.weight_nn is not None else None
+            if w is None:
+                w = self.tp.weight.unsqueeze(0).expand(ordering.n_edges, -1).contiguous()
+            data[DataKey.EDGE_MESSAGE] = self.tp.tp(x, data[DataKey.EDGE_ATTRS], w, ordering, 1.0, per_edge=True)
+        return data
+
+
+class PointConvUpdate(ModuleIrreps, torch.nn.Module):
+    """eigenn/nn/point_conv.py:90-194"""
+
+    REQUIRED_KEYS_IRREPS_IN = [DataKey.NODE_FEATURES, DataKey.NODE_ATTRS, DataKey.EDGE_MESSAGE, DataKey.EDGE_INDEX]
+
+    def __init__(self, irreps_in: Dict[str, Irreps], irreps_out: Dict[str, Irreps], *, use_self_connection: bool = True, avg_num_neighbors: Optional[float] = None):
+        super().__init__()
+        self.avg_num_neighbors = avg_num_neighbors
+        self.init_irreps(irreps_in, irreps_out)
+        node_in = self.irreps_in[DataKey.NODE_FEATURES]
+        node_out = self.irreps_out[DataKey.NODE_FEATURES]
+        self.linear_2 = Linear(self.irreps_in[DataKey.EDGE_MESSAGE], node_out)
+        if use_self_connection:
+            self.self_connection = FullyConnectedTensorProduct(node_in, self.irreps_in[DataKey.NODE_ATTRS], node_out)
+        else:
+            self.self_connection = None
+
+    @property
+    def aggregation_scale(self) -> float:
+        return 1.0 if self.avg_num_neighbors is None else float(self.avg_num_neighbors) ** -0.5
+
+    def forward(self, data: DataKey.Type) -> DataKey.Type:
+        node_feats = data[DataKey.NODE_FEATURES]
+        if _NODE_MESSAGE in data:  # summed and scaled inside the convolution kernel
+            msg = data.pop(_NODE_MESSAGE)
+        else:
+            edge_src, edge_dst = data[DataKey.EDGE_INDEX]
+            msg = scatter_add(data[DataKey.EDGE_MESSAGE], edge_dst, dim_size=len(node_feats))
+            if self.avg_num_neighbors is not None:
+                msg = msg * self.aggregation_scale
+        msg = self.linear_2(msg)
+        if self.self_connection is not None:
+            # out = msg + self_connection(x, attrs), accumulated into msg's buffer by the GEMM
+            node_feats = self.self_connection(node_feats, data[DataKey.NODE_ATTRS], base=msg)
+        else:
+            node_feats = msg
+        data[DataKey.NODE_FEATURES] = node_feats
+        return data
+
+
+@compile_mode("script")
+class PointConvMessagePassing(ModuleIrreps, torch.nn.Module):
+    """eigenn/nn/point_conv.py:197-347: message -> update -> Gate -> optional residual."""
+
+    def __init__(
+        self,
+        irreps_in: Dict[str, Irreps],
+        conv_layer_irreps: Irreps,
+        message=PointConvMessage,
+        update=PointConvUpdate,
+        message_kwargs: Optional[Dict] = None,
+        update_kwargs: Optional[Dict] = None,
+        activation_type: str = "gate",
+        activation_scalars: Dict[str, str] = None,
+        activation_gates: Dict[str, str] = None,
+        use_resnet: bool = True,
+    ):
+        super().__init__()
+        message_kwargs = {} if message_kwargs is None else dict(message_kwargs)
+        update_kwargs = {} if update_kwargs is None else dict(update_kwargs)
+        self.init_irreps(irreps_in)
+        edge_attrs_irreps = self.irreps_in[DataKey.EDGE_ATTRS]
+        node_in = self.irreps_in[DataKey.NODE_FEATURES]
+
+        self.equivariant_nonlinear = ActivationLayer(
+            tp_irreps_in1=node_in,
+            tp_irreps_in2=edge_attrs_irreps,
+            tp_irreps_out=conv_layer_irreps,
+            activation_type=activation_type,
+            activation_scalars=activation_scalars,
+            activation_gates=activation_gates,
+        )
+        irreps_before_act = self.equivariant_nonlinear.irreps_in
+        irreps_after_act = self.equivariant_nonlinear.irreps_out
+
+        message_kwargs.pop("irreps_in", None)
+        message_kwargs.pop("irreps_out", None)
+        self.message_fn = message(irreps_in=self.irreps_in, irreps_out={DataKey.NODE_FEATURES: irreps_before_act}, **message_kwargs)
+
+        update_fn_irreps_in = dict(self.irreps_in)
+        update_fn_irreps_in[DataKey.EDGE_MESSAGE] = self.message_fn.irreps_out[DataKey.EDGE_MESSAGE]
+        update_kwargs.pop("irreps_in", None)
+        update_kwargs.pop("irreps_out", None)
+        self.update_fn = update(irreps_in=update_fn_irreps_in, irreps_out={DataKey.NODE_FEATURES: irreps_before_act}, **update_kwargs)
+
+        if isinstance(self.message_fn, PointConvMessage) and isinstance(self.update_fn, PointConvUpdate):
+            self.message_fn.fuse_aggregation = True
+            self.message_fn.aggregation_scale = self.update_fn.aggregation_scale
+
+        self.use_resnet = bool(use_resnet and irreps_after_act == node_in)
+        self.irreps_out.update(self.update_fn.irreps_out)
+        self.irreps_out[DataKey.NODE_FEATURES] = irreps_after_act
+
+    def forward(self, data: DataKey.Type) -> DataKey.Type:
+        old_x = data[DataKey.NODE_FEATURES]
+        data = self.message_fn(data)
+        data = self.update_fn(data)
+        x = self.equivariant_nonlinear(data[DataKey.NODE_FEATURES])
+        data[DataKey.NODE_FEATURES] = old_x + x if self.use_resnet else x
+        return data
+
+
+class PointConv(ModuleIrreps, torch.nn.Module):
+    """Legacy single-module form, eigenn/nn/point_conv.py:351-491 (explicit irreps_out, no
+    activation).  Constructs for any irreps (as the reference's tests/nn/test_convolution.py
+    does); calling it needs irreps the kernels cover."""
+
+    REQUIRED_KEYS_IRREPS_IN = [
+        DataKey.NODE_FEATURES,
+        DataKey.NODE_ATTRS,
+        DataKey.EDGE_EMBEDDING,
+        DataKey.EDGE_ATTRS,
+        DataKey.EDGE_INDEX,
+    ]
+    REQUIRED_TYPE_IRREPS_IN = {DataKey.EDGE_EMBEDDING: "0e"}
+
+    def __init__(
+        self,
+        irreps_in: Dict[str, Irreps],
+        irreps_out: Dict[str, Irreps],
+        *,
+        fc_num_hidden_layers: int = 1,
+        fc_hidden_size: int = 8,
+        use_self_connection: bool = True,
+        avg_num_neighbors: Optional[float] = None,
+    ):
+        super().__init__()
+        self.avg_num_neighbors = avg_num_neighbors
+        self.init_irreps(irreps_in, irreps_out)
+        node_in = self.irreps_in[DataKey.NODE_FEATURES]
+        node_out = self.irreps_out[DataKey.NODE_FEATURES]
+        self.linear_1 = Linear(node_in, node_in)
+        self.tp = UVUTensorProduct(
+            node_in,
+            self.irreps_in[DataKey.EDGE_ATTRS],
+            node_out,
+            mlp_input_size=self.irreps_in[DataKey.EDGE_EMBEDDING].dim,
+            mlp_hidden_size=fc_hidden_size,
+            mlp_num_hidden_layers=fc_num_hidden_layers,
+        )
+        self.linear_2 = Linear(self.tp.irreps_out, node_out)
+        if use_self_connection:
+            self.self_connection = FullyConnectedTensorProduct(node_in, self.irreps_in[DataKey.NODE_ATTRS], node_out)
+        else:
+            self.self_connection = None
+
+    def forward(self, data: DataKey.Type) -> DataKey.Type:
+        data = data.copy()
+        x_in = data[DataKey.NODE_FEATURES]
+        x = self.linear_1(x_in)
+        ordering = ops.edge_ordering(data[DataKey.EDGE_INDEX], x.shape[0])
+        scale = 1.0 if self.avg_num_neighbors is None else float(self.avg_num_neighbors) ** -0.5
+        msg = self.tp(x, data[DataKey.EDGE_ATTRS], data[DataKey.EDGE_EMBEDDING], ordering=ordering, scale=scale)
+        msg = self.linear_2(msg)
+        if self.self_connection is not None:
+            msg = self.self_connection(x_in, data[DataKey.NODE_ATTRS], base=msg)
+        data[DataKey.NODE_FEATURES] = msg
+        return data

@@ -1,0 +1,743 @@
+"""Autograd wrappers around the libtfc C ABI (include/tfc.h).
+
+PyTorch is the host here: it owns device memory, streams and the autograd graph.  Every
+`torch.autograd.Function` below allocates its outputs and scratch with torch, hands raw
+device pointers to the HIP kernels on torch's current stream, and implements the backward
+the reference obtains from autograd (the reference has no custom Function anywhere,
+SURVEY.md §3.3).  There is no CPU / eager fallback: tensors must live on a ROCm device.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+import weakref
+from dataclasses import dataclass
+from typing import List, Optional, Sequence, Tuple
+
+import torch
+
+from . import _lib
+from ._lib import GateSeg, GemmDesc, IMap, Path
+
+__all__ = [
+    "EdgeOrdering",
+    "edge_ordering",
+    "ConvPlan",
+    "conv",
+    "scatter_add",
+    "edge_geometry",
+    "spherical_harmonics",
+    "radial_embedding",
+    "LinearSpec",
+    "linear",
+    "radial_mlp",
+    "FctpSpec",
+    "fctp",
+    "GateSpec",
+    "gate",
+]
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _ptr(t: Optional[torch.Tensor], offset: int = 0):
+    if t is None:
+        return None
+    return C.c_void_p(t.data_ptr() + offset * t.element_size())
+
+
+def _f32(t: torch.Tensor, name: str) -> torch.Tensor:
+    if not t.is_cuda:
+        raise RuntimeError(f"matten_amd: `{name}` must live on a ROCm device (no CPU fallback exists); got {t.device}")
+    if t.dtype != torch.float32:
+        raise TypeError(f"matten_amd: `{name}` must be float32, got {t.dtype}")
+    return t.contiguous()
+
+
+# ======================================================================================
+# edge ordering
+# ======================================================================================
+
+
+class EdgeOrdering:
+    """The two groupings of the edge list the kernels reduce over (tfc_csr_build):
+    by receiver edge_index[1] (forward: sum of messages) and by sender edge_index[0]
+    (backward: gradient of the gathered sender features)."""
+
+    def __init__(self, edge_index: torch.Tensor, n_nodes: int):
+        if edge_index.dim() != 2 or edge_index.shape[0] != 2:
+            raise ValueError(f"edge_index must have shape [2, E], got {tuple(edge_index.shape)}")
+        if not edge_index.is_cuda:
+            raise RuntimeError("matten_amd: edge_index must live on a ROCm device (no CPU fallback exists)")
+        ei = edge_index.to(torch.int64).contiguous()
+        self.edge_index = ei
+        self.n_nodes = int(n_nodes)
+        self.n_edges = int(ei.shape[1])
+        dev = ei.device
+        E, N = self.n_edges, self.n_nodes
+        L = _lib.lib()
+        self.status = torch.zeros(2, dtype=torch.int32, device=dev)
+        ws = torch.empty(max(int(L.tfc_csr_workspace_bytes(N, E)), 8), dtype=torch.uint8, device=dev)
+
+        def build(key_row, other_row, slot):
+            rp = torch.empty(N + 1, dtype=torch.int32, device=dev)
+            eid = torch.empty(max(E, 1), dtype=torch.int32, device=dev)
+            nbr = torch.empty(max(E, 1), dtype=torch.int32, device=dev)
+            _lib.check(
+                L.tfc_csr_build(
+                    _ptr(ei, key_row * E), _ptr(ei, other_row * E), E, N, _ptr(rp), _ptr(eid), _ptr(nbr),
+                    _ptr(self.status, slot), _ptr(ws), _stream(),
+                )
+            )
+            return rp, eid, nbr
+
+        self.by_dst = build(1, 0, 0)  # centre = receiver, nbr = sender
+        self.by_src = build(0, 1, 1)  # centre = sender,   nbr = receiver
+        self._edge_rows = None
+
+    def per_edge(self):
+        """Ordering in which every edge is its own centre (used to materialise per-edge
+        messages for callers that want the unfused EDGE_MESSAGE tensor)."""
+        if self._edge_rows is None:
+            dev = self.edge_index.device
+            E = self.n_edges
+            rp = torch.arange(E + 1, dtype=torch.int32, device=dev)
+            eid = torch.arange(max(E, 1), dtype=torch.int32, device=dev)
+            nbr = self.edge_index[0].to(torch.int32).contiguous() if E else eid
+            self._edge_rows = (rp, eid, nbr)
+        return self._edge_rows
+
+    def validate(self):
+        """Synchronises: raises if any index was outside [0, n_nodes)."""
+        if int(self.status.max().item()) != 0:
+            raise IndexError("edge_index contains node ids outside [0, n_nodes)")
+
+
+_ORDER_CACHE: "dict[int, tuple]" = {}
+
+
+def edge_ordering(edge_index: torch.Tensor, n_nodes: int) -> EdgeOrdering:
+    """Ordering for this edge_index tensor, built once and shared by all layers (and by
+    forward and backward) that see the same tensor object."""
+    key = id(edge_index)
+    hit = _ORDER_CACHE.get(key)
+    if hit is not None:
+        ref, version, n, ordering = hit
+        if ref() is edge_index and version == edge_index._version and n == n_nodes:
+            return ordering
+    ordering = EdgeOrdering(edge_index, n_nodes)
+    if len(_ORDER_CACHE) > 64:
+        for k in [k for k, v in _ORDER_CACHE.items() if v[0]() is None]:
+            _ORDER_CACHE.pop(k, None)
+        while len(_ORDER_CACHE) > 64:
+            _ORDER_CACHE.pop(next(iter(_ORDER_CACHE)))
+    _ORDER_CACHE[key] = (weakref.ref(edge_index), edge_index._version, n_nodes, ordering)
+    return ordering
+
+
+# ======================================================================================
+# fused gather + uvu tensor product + per-node sum
+# ======================================================================================
+
+
+class ConvPlan:
+    """Host handle of a tfc_conv_plan (device tables live on the device that was current
+    when the plan was first used)."""
+
+    def __init__(self, paths: Sequence[dict], d_in: int, d_sh: int, d_out: int, w_numel: int):
+        self.paths = [dict(p) for p in paths]
+        self.d_in, self.d_sh, self.d_out, self.w_numel = int(d_in), int(d_sh), int(d_out), int(w_numel)
+        self._handles = {}
+
+    def handle(self, device: torch.device):
+        idx = device.index if device.index is not None else torch.cuda.current_device()
+        h = self._handles.get(idx)
+        if h is None:
+            arr = (Path * len(self.paths))()
+            for a, p in zip(arr, self.paths):
+                a.l1, a.l2, a.l3, a.mul = p["l1"], p["l2"], p["l3"], p["mul"]
+                a.x_off, a.y_off, a.out_off, a.w_off = p["x_off"], p["y_off"], p["out_off"], p["w_off"]
+                a.coeff = p["coeff"]
+            out = C.c_void_p()
+            with torch.cuda.device(idx):
+                _lib.check(
+                    _lib.lib().tfc_conv_plan_create(arr, len(self.paths), self.d_in, self.d_sh, self.d_out, self.w_numel, C.byref(out))
+                )
+            h = out
+            self._handles[idx] = h
+        return h
+
+    def workspace(self, device, n_edges: int, need_dy: bool) -> torch.Tensor:
+        n = int(_lib.lib().tfc_conv_workspace_floats(self.handle(device), n_edges, 1 if need_dy else 0))
+        return torch.empty(max(n, 1), dtype=torch.float32, device=device)
+
+    def __del__(self):
+        try:
+            for h in self._handles.values():
+                _lib.lib().tfc_conv_plan_destroy(h)
+        except Exception:
+            pass
+
+
+class _ConvFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, y, w, plan: ConvPlan, fwd_rows, bwd_rows, n_out: int, scale: float):
+        x, y, w = _f32(x, "x"), _f32(y, "edge_attrs"), _f32(w, "weights")
+        E = y.shape[0]
+        if x.shape[1] != plan.d_in or y.shape[1] != plan.d_sh or w.shape[1] != plan.w_numel or w.shape[0] != E:
+            raise ValueError(
+                f"conv: shapes x{tuple(x.shape)} y{tuple(y.shape)} w{tuple(w.shape)} do not match the plan "
+                f"(d_in={plan.d_in}, d_sh={plan.d_sh}, w_numel={plan.w_numel})"
+            )
+        rp, eid, nbr = fwd_rows
+        if rp.numel() != n_out + 1:
+            raise ValueError("conv: ordering does not match the number of output rows")
+        out = torch.empty(n_out, plan.d_out, dtype=torch.float32, device=x.device)
+        ws = plan.workspace(x.device, E, False)
+        _lib.check(
+            _lib.lib().tfc_conv_fwd(
+                plan.handle(x.device), _ptr(x), _ptr(y), _ptr(w), _ptr(rp), _ptr(eid), _ptr(nbr), n_out, E,
+                float(scale), _ptr(out), _ptr(ws), _stream(),
+            )
+        )
+        ctx.save_for_backward(x, y, w)
+        ctx.plan, ctx.bwd_rows, ctx.scale = plan, bwd_rows, float(scale)
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        x, y, w = ctx.saved_tensors
+        plan = ctx.plan
+        gout = _f32(gout, "grad_output")
+        E = y.shape[0]
+        need_dy = ctx.needs_input_grad[1]
+        rp, eid, nbr = ctx.bwd_rows
+        dx = torch.empty_like(x)
+        dw = torch.empty_like(w)
+        dy = torch.empty_like(y) if need_dy else None
+        ws = plan.workspace(x.device, E, need_dy)
+        _lib.check(
+            _lib.lib().tfc_conv_bwd(
+                plan.handle(x.device), _ptr(x), _ptr(y), _ptr(w), _ptr(gout), _ptr(rp), _ptr(eid), _ptr(nbr),
+                x.shape[0], E, ctx.scale, _ptr(dx), _ptr(dw), _ptr(dy), _ptr(ws), _stream(),
+            )
+        )
+        return dx, dy, dw, None, None, None, None, None
+
+
+def conv(x, y, w, plan: ConvPlan, ordering: EdgeOrdering, scale: float = 1.0, per_edge: bool = False):
+    """out[n] = scale * sum_{e -> n} TP_uvu(x[sender(e)], y[e]; w[e]); `per_edge=True`
+    returns the un-summed messages [E, d_out] instead (each edge is its own row)."""
+    if per_edge:
+        rps, eids, _ = ordering.by_src  # backward gathers the gradient row of the edge itself
+        return _ConvFn.apply(x, y, w, plan, ordering.per_edge(), (rps, eids, eids), ordering.n_edges, scale)
+    return _ConvFn.apply(x, y, w, plan, ordering.by_dst, ordering.by_src, ordering.n_nodes, scale)
+
+
+class _ScatterAddFn(torch.autograd.Function):
+    """scatter_add over dim 0 as a fixed-order sum over each destination's rows; backward is a
+    row gather."""
+
+    @staticmethod
+    def forward(ctx, src, index, dim_size: int):
+        src = _f32(src, "src")
+        index = index.to(torch.int64).contiguous()
+        e, d = src.shape
+        ident = torch.arange(e, dtype=torch.int64, device=src.device)
+        order = EdgeOrdering(torch.stack([index, ident]), max(int(dim_size), e))
+        rp, eid, _ = order.by_src  # grouped by `index`
+        out = torch.empty(order.n_nodes, d, dtype=torch.float32, device=src.device)
+        _lib.check(_lib.lib().tfc_segment_sum(_ptr(src), _ptr(rp), _ptr(eid), order.n_nodes, d, _ptr(out), _stream()))
+        ctx.save_for_backward(index)
+        ctx.n_src = e
+        return out[:dim_size]
+
+    @staticmethod
+    def backward(ctx, g):
+        (index,) = ctx.saved_tensors
+        g = _f32(g, "grad_output")
+        d = g.shape[1]
+        out = torch.empty(ctx.n_src, d, dtype=torch.float32, device=g.device)
+        _lib.check(_lib.lib().tfc_gather_rows(_ptr(g), _ptr(index), ctx.n_src, g.shape[0], d, _ptr(out), _stream()))
+        return out, None, None
+
+
+def scatter_add(src, index, dim_size: int):
+    return _ScatterAddFn.apply(src, index, dim_size)
+
+
+# ======================================================================================
+# per-edge encoders
+# ======================================================================================
+
+
+def _dvec_to_dpos(dvec, ordering: EdgeOrdering):
+    dpos = torch.empty(ordering.n_nodes, 3, dtype=torch.float32, device=dvec.device)
+    if ordering.n_edges == 0:
+        return dpos.zero_()
+    rps, eids, _ = ordering.by_src
+    rpd, eidd, _ = ordering.by_dst
+    _lib.check(
+        _lib.lib().tfc_edge_vec_bwd(_ptr(dvec), _ptr(rps), _ptr(eids), _ptr(rpd), _ptr(eidd), ordering.n_nodes, _ptr(dpos), _stream())
+    )
+    return dpos
+
+
+class _EdgeGeometryFn(torch.autograd.Function):
+    """pos (+ periodic shifts) -> edge vectors, lengths and, optionally, spherical harmonics."""
+
+    @staticmethod
+    def forward(ctx, pos, shift, cell, batch, ordering: EdgeOrdering, lmax: int):
+        pos = _f32(pos, "pos")
+        ei = ordering.edge_index
+        E, N = ordering.n_edges, pos.shape[0]
+        dev = pos.device
+        vec = torch.empty(E, 3, dtype=torch.float32, device=dev)
+        length = torch.empty(E, dtype=torch.float32, device=dev)
+        sh = torch.empty(E, (lmax + 1) ** 2, dtype=torch.float32, device=dev) if lmax >= 0 else None
+        if shift is not None:
+            shift = _f32(shift, "edge_cell_shift")
+            cell = _f32(cell, "cell").reshape(-1, 3, 3)
+            G = cell.shape[0]
+            if G > 1:
+                if batch is None:
+                    raise ValueError("a batched cell needs `batch`")
+                batch = batch.to(torch.int64).contiguous()
+            else:
+                batch = None
+        else:
+            cell, batch, G = None, None, 1
+        if E:
+            _lib.check(
+                _lib.lib().tfc_edge_encode_fwd(
+                    _ptr(pos), _ptr(ei), _ptr(shift), _ptr(cell), _ptr(batch), E, N, G, max(lmax, 0), None, 0,
+                    1.0, 6.0, _ptr(vec), _ptr(length), _ptr(sh), None, _stream(),
+                )
+            )
+        ctx.save_for_backward(vec, length)
+        ctx.ordering, ctx.lmax = ordering, lmax
+        ctx.set_materialize_grads(False)
+        if sh is None:
+            return vec, length
+        return vec, length, sh
+
+    @staticmethod
+    def backward(ctx, dvec_in, dlen, dsh=None):
+        vec, length = ctx.saved_tensors
+        E = vec.shape[0]
+        dvec = torch.empty_like(vec)
+        if E:
+            _lib.check(
+                _lib.lib().tfc_edge_encode_bwd(
+                    _ptr(vec), _ptr(length), E, max(ctx.lmax, 0), None, 0, 1.0, 6.0,
+                    _ptr(_f32(dsh, "dsh")) if dsh is not None else None, None,
+                    _ptr(_f32(dvec_in, "dvec")) if dvec_in is not None else None,
+                    _ptr(_f32(dlen, "dlen")) if dlen is not None else None, _ptr(dvec), None, _stream(),
+                )
+            )
+        return _dvec_to_dpos(dvec, ctx.ordering), None, None, None, None, None
+
+
+def edge_geometry(pos, ordering: EdgeOrdering, shift=None, cell=None, batch=None, lmax: int = -1):
+    """(vec, len) or (vec, len, sh) from positions; differentiable w.r.t. `pos`.  (The
+    reference's graph is also differentiable w.r.t. `cell`; that gradient is not provided.)"""
+    if cell is not None and cell.requires_grad:
+        raise NotImplementedError("matten_amd: gradient with respect to `cell` is not implemented")
+    return _EdgeGeometryFn.apply(pos, shift, cell, batch, ordering, lmax)
+
+
+class _ShFn(torch.autograd.Function):
+    """Spherical harmonics of caller-supplied edge vectors."""
+
+    @staticmethod
+    def forward(ctx, vec, lmax: int):
+        vec = _f32(vec, "edge_vectors")
+        E = vec.shape[0]
+        sh = torch.empty(E, (lmax + 1) ** 2, dtype=torch.float32, device=vec.device)
+        if E:
+            # len = null: the kernel takes the lengths from the vectors themselves
+            _lib.check(
+                _lib.lib().tfc_edge_encode_fwd(
+                    None, None, None, None, None, E, 0, 1, lmax, None, 0, 1.0, 6.0, _ptr(vec), None, _ptr(sh),
+                    None, _stream(),
+                )
+            )
+        ctx.save_for_backward(vec)
+        ctx.lmax = lmax
+        return sh
+
+    @staticmethod
+    def backward(ctx, dsh):
+        (vec,) = ctx.saved_tensors
+        dvec = torch.empty_like(vec)
+        if vec.shape[0]:
+            _lib.check(
+                _lib.lib().tfc_edge_encode_bwd(
+                    _ptr(vec), None, vec.shape[0], ctx.lmax, None, 0, 1.0, 6.0, _ptr(_f32(dsh, "dsh")), None,
+                    None, None, _ptr(dvec), None, _stream(),
+                )
+            )
+        return dvec, None
+
+
+def spherical_harmonics(vec, lmax: int):
+    return _ShFn.apply(vec, lmax)
+
+
+class _RadialFn(torch.autograd.Function):
+    """Bessel basis x polynomial cutoff of the edge length.  The length enters through the
+    edge vector, so the gradient is returned on `vec` directly."""
+
+    @staticmethod
+    def forward(ctx, vec, length, bessel_weights, r_max: float, p: float):
+        vec, length, bw = _f32(vec, "edge_vectors"), _f32(length, "edge_lengths"), _f32(bessel_weights, "bessel_weights")
+        E, B = vec.shape[0], bw.shape[0]
+        emb = torch.empty(E, B, dtype=torch.float32, device=vec.device)
+        if E:
+            _lib.check(
+                _lib.lib().tfc_edge_encode_fwd(
+                    None, None, None, None, None, E, 0, 1, 0, _ptr(bw), B, float(r_max), float(p), _ptr(vec),
+                    _ptr(length), None, _ptr(emb), _stream(),
+                )
+            )
+        ctx.save_for_backward(vec, length, bw)
+        ctx.r_max, ctx.p = float(r_max), float(p)
+        return emb
+
+    @staticmethod
+    def backward(ctx, demb):
+        vec, length, bw = ctx.saved_tensors
+        E, B = vec.shape[0], bw.shape[0]
+        dvec = torch.empty_like(vec)
+        dbw = None
+        if E == 0:
+            return dvec, None, torch.zeros_like(bw) if ctx.needs_input_grad[2] else None, None, None
+        nb = int(_lib.lib().tfc_edge_bwd_blocks(E))
+        part = torch.empty(nb, B, dtype=torch.float32, device=vec.device) if ctx.needs_input_grad[2] else None
+        _lib.check(
+            _lib.lib().tfc_edge_encode_bwd(
+                _ptr(vec), _ptr(length), E, 0, _ptr(bw), B, ctx.r_max, ctx.p, None, _ptr(_f32(demb, "demb")), None,
+                None, _ptr(dvec), _ptr(part), _stream(),
+            )
+        )
+        if part is not None:
+            dbw = part.sum(dim=0)  # second stage of the fixed-shape two-stage sum
+        return dvec, None, dbw, None, None
+
+
+def radial_embedding(vec, length, bessel_weights, r_max: float, p: float = 6.0):
+    return _RadialFn.apply(vec, length, bessel_weights, r_max, p)
+
+
+# ======================================================================================
+# dense pieces on the fp32 matrix cores
+# ======================================================================================
+
+
+def _imap(d1=1, d2=1, s0=0, s1=0, s2=0) -> IMap:
+    return IMap(int(d1), int(d2), int(s0), int(s1), int(s2))
+
+
+def _lin(stride) -> IMap:  # f(t) = t * stride
+    return _imap(1, 1, stride, 0, 0)
+
+
+def _gemm(m, n, k, a1, b, c, a1_r, a1_k, b_k, b_j, c_r, c_j, alpha=1.0, accumulate=False, a2=None, a2_r=None, a2_k=None,
+          epilogue=_lib.EPI_NONE, aux=None, act_cst=1.0):
+    d = GemmDesc()
+    d.m, d.n, d.k = int(m), int(n), int(k)
+    d.a1, d.b, d.c = a1, b, c
+    d.a2 = a2
+    d.a1_r, d.a1_k = a1_r, a1_k
+    d.a2_r = a2_r if a2_r is not None else _lin(0)
+    d.a2_k = a2_k if a2_k is not None else _lin(0)
+    d.b_k, d.b_j, d.c_r, d.c_j = b_k, b_j, c_r, c_j
+    d.alpha = float(alpha)
+    d.accumulate = 1 if accumulate else 0
+    d.epilogue = int(epilogue)
+    d.aux = aux
+    d.act_cst = float(act_cst)
+    _lib.check(_lib.lib().tfc_gemm(C.byref(d), _stream()))
+
+
+def _p(t: torch.Tensor, off: int = 0):
+    return t.data_ptr() + 4 * int(off)
+
+
+# ------------------------------------------------------------------ o3.Linear
+
+
+@dataclass(frozen=True)
+class LinearSpec:
+    """o3.Linear as a list of instructions (in_off, mul_in, out_off, mul_out, dim, w_off, path_weight)."""
+
+    d_in: int
+    d_out: int
+    weight_numel: int
+    instructions: Tuple[Tuple[int, int, int, int, int, int, float], ...]
+    out_covered: bool  # every output column is written by some instruction
+    in_covered: bool
+
+
+class _LinearFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, spec: LinearSpec):
+        x, weight = _f32(x, "x"), _f32(weight, "weight")
+        n = x.shape[0]
+        if x.shape[1] != spec.d_in or weight.numel() != spec.weight_numel:
+            raise ValueError(f"linear: x{tuple(x.shape)} / weight[{weight.numel()}] do not match the irreps ({spec.d_in}, {spec.weight_numel})")
+        alloc = torch.empty if spec.out_covered else torch.zeros
+        out = alloc(n, spec.d_out, dtype=torch.float32, device=x.device)
+        seen = set()
+        for in_off, mi, out_off, mo, d, w_off, pw in spec.instructions:
+            _gemm(
+                n * d, mo, mi, _p(x, in_off), _p(weight, w_off), _p(out, out_off),
+                a1_r=_imap(1, d, spec.d_in, 0, 1), a1_k=_lin(d), b_k=_lin(mo), b_j=_lin(1),
+                c_r=_imap(1, d, spec.d_out, 0, 1), c_j=_lin(d), alpha=pw, accumulate=out_off in seen,
+            )
+            seen.add(out_off)
+        ctx.save_for_backward(x, weight)
+        ctx.spec = spec
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        x, weight = ctx.saved_tensors
+        spec = ctx.spec
+        g = _f32(g, "grad_output")
+        n = x.shape[0]
+        dx = dw = None
+        if ctx.needs_input_grad[0]:
+            alloc = torch.empty if spec.in_covered else torch.zeros
+            dx = alloc(n, spec.d_in, dtype=torch.float32, device=x.device)
+            seen = set()
+            for in_off, mi, out_off, mo, d, w_off, pw in spec.instructions:
+                _gemm(
+                    n * d, mi, mo, _p(g, out_off), _p(weight, w_off), _p(dx, in_off),
+                    a1_r=_imap(1, d, spec.d_out, 0, 1), a1_k=_lin(d), b_k=_lin(1), b_j=_lin(mo),
+                    c_r=_imap(1, d, spec.d_in, 0, 1), c_j=_lin(d), alpha=pw, accumulate=in_off in seen,
+                )
+                seen.add(in_off)
+        if ctx.needs_input_grad[1]:
+            dw = torch.empty_like(weight)
+            for in_off, mi, out_off, mo, d, w_off, pw in spec.instructions:
+                _gemm(
+                    mi, mo, n * d, _p(x, in_off), _p(g, out_off), _p(dw, w_off),
+                    a1_r=_lin(d), a1_k=_imap(1, d, spec.d_in, 0, 1), b_k=_imap(1, d, spec.d_out, 0, 1), b_j=_lin(d),
+                    c_r=_lin(mo), c_j=_lin(1), alpha=pw,
+                )
+        return dx, dw, None
+
+
+def linear(x, weight, spec: LinearSpec):
+    return _LinearFn.apply(x, weight, spec)
+
+
+# ------------------------------------------------------------------ radial FullyConnectedNet
+
+
+class _RadialMlpFn(torch.autograd.Function):
+    """x -> act'(x W0/sqrt(h0)) -> ... -> h W_last/sqrt(h_last); act' = cst * ssp."""
+
+    @staticmethod
+    def forward(ctx, x, act_cst: float, *weights):
+        x = _f32(x, "edge_embedding")
+        ws = [_f32(w, "mlp weight") for w in weights]
+        E = x.shape[0]
+        hs = [x]
+        for i, w in enumerate(ws):
+            hin, hout = w.shape
+            if hs[-1].shape[1] != hin:
+                raise ValueError(f"radial mlp: layer {i} expects {hin} inputs, got {hs[-1].shape[1]}")
+            out = torch.empty(E, hout, dtype=torch.float32, device=x.device)
+            last = i == len(ws) - 1
+            _gemm(
+                E, hout, hin, _p(hs[-1]), _p(w), _p(out), a1_r=_lin(hin), a1_k=_lin(1), b_k=_lin(hout), b_j=_lin(1),
+                c_r=_lin(hout), c_j=_lin(1), alpha=1.0 / math.sqrt(hin),
+                epilogue=_lib.EPI_NONE if last else _lib.EPI_SSP, act_cst=act_cst,
+            )
+            hs.append(out)
+        ctx.save_for_backward(*hs[:-1], *ws)
+        ctx.n_layers, ctx.act_cst = len(ws), float(act_cst)
+        return hs[-1]
+
+    @staticmethod
+    def backward(ctx, g):
+        L = ctx.n_layers
+        hs, ws = ctx.saved_tensors[:L], ctx.saved_tensors[L:]
+        g = _f32(g, "grad_output")
+        E = g.shape[0]
+        dws: List[Optional[torch.Tensor]] = [None] * L
+        for i in range(L - 1, -1, -1):
+            w, h = ws[i], hs[i]
+            hin, hout = w.shape
+            alpha = 1.0 / math.sqrt(hin)
+            if ctx.needs_input_grad[2 + i]:
+                dw = torch.empty_like(w)
+                _gemm(
+                    hin, hout, E, _p(h), _p(g), _p(dw), a1_r=_lin(1), a1_k=_lin(hin), b_k=_lin(hout), b_j=_lin(1),
+                    c_r=_lin(hout), c_j=_lin(1), alpha=alpha,
+                )
+                dws[i] = dw
+            if i > 0 or ctx.needs_input_grad[0]:
+                dh = torch.empty(E, hin, dtype=torch.float32, device=g.device)
+                _gemm(
+                    E, hin, hout, _p(g), _p(w), _p(dh), a1_r=_lin(hout), a1_k=_lin(1), b_k=_lin(1), b_j=_lin(hout),
+                    c_r=_lin(hin), c_j=_lin(1), alpha=alpha,
+                    epilogue=_lib.EPI_SSP_GRAD if i > 0 else _lib.EPI_NONE, aux=_p(h) if i > 0 else None,
+                    act_cst=ctx.act_cst,
+                )
+                g = dh
+            else:
+                g = None
+        return (g if ctx.needs_input_grad[0] else None, None, *dws)
+
+
+def radial_mlp(x, weights: Sequence[torch.Tensor], act_cst: float):
+    return _RadialMlpFn.apply(x, act_cst, *weights)
+
+
+# ------------------------------------------------------------------ FullyConnectedTensorProduct with scalar second input
+
+
+@dataclass(frozen=True)
+class FctpSpec:
+    """Self connection: instructions (x_off, mul_u, a_off, mul_v, out_off, mul_w, dim, w_off, alpha)
+    with out[n,w,k] += alpha * sum_{u,v} W[u,v,w] x[n,u,k] a[n,v]  (second input scalar, l2 = 0)."""
+
+    d_x: int
+    d_a: int
+    d_out: int
+    weight_numel: int
+    instructions: Tuple[Tuple[int, int, int, int, int, int, int, int, float], ...]
+    out_covered: bool
+    x_covered: bool
+    a_covered: bool
+
+
+class _FctpFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, a, weight, spec: FctpSpec, base):
+        x, a, weight = _f32(x, "x"), _f32(a, "node_attrs"), _f32(weight, "weight")
+        n = x.shape[0]
+        if x.shape[1] != spec.d_x or a.shape[1] != spec.d_a or weight.numel() != spec.weight_numel:
+            raise ValueError("fctp: tensor shapes do not match the irreps")
+        if base is not None:
+            if not base.is_contiguous() or base.shape != (n, spec.d_out):
+                raise ValueError("fctp: `base` must be a contiguous [N, d_out] tensor")
+            out = base
+            ctx.mark_dirty(base)
+            seen = None
+        else:
+            alloc = torch.empty if spec.out_covered else torch.zeros
+            out = alloc(n, spec.d_out, dtype=torch.float32, device=x.device)
+            seen = set()
+        for xo, mu, ao, mv, oo, mw, d, wo, alpha in spec.instructions:
+            _gemm(
+                n * d, mw, mu * mv, _p(x, xo), _p(weight, wo), _p(out, oo),
+                a1_r=_imap(1, d, spec.d_x, 0, 1), a1_k=_imap(1, mv, d, 0, 0),
+                a2=_p(a, ao), a2_r=_imap(1, d, spec.d_a, 0, 0), a2_k=_imap(1, mv, 0, 0, 1),
+                b_k=_lin(mw), b_j=_lin(1), c_r=_imap(1, d, spec.d_out, 0, 1), c_j=_lin(d), alpha=alpha,
+                accumulate=True if seen is None else (oo in seen),
+            )
+            if seen is not None:
+                seen.add(oo)
+        ctx.save_for_backward(x, a, weight)
+        ctx.spec = spec
+        ctx.has_base = base is not None
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        x, a, weight = ctx.saved_tensors
+        spec = ctx.spec
+        g = _f32(g, "grad_output")
+        n = x.shape[0]
+        dx = da = dw = None
+        if ctx.needs_input_grad[0]:
+            dx = (torch.empty if spec.x_covered else torch.zeros)(n, spec.d_x, dtype=torch.float32, device=x.device)
+            seen = set()
+            for xo, mu, ao, mv, oo, mw, d, wo, alpha in spec.instructions:
+                # dx[(n,k), u] = sum_{(v,w)} a[n,v] g[n,w,k] W[u,v,w]
+                _gemm(
+                    n * d, mu, mv * mw, _p(a, ao), _p(weight, wo), _p(dx, xo),
+                    a1_r=_imap(1, d, spec.d_a, 0, 0), a1_k=_imap(1, mw, 1, 0, 0),
+                    a2=_p(g, oo), a2_r=_imap(1, d, spec.d_out, 0, 1), a2_k=_imap(1, mw, 0, 0, d),
+                    b_k=_lin(1), b_j=_lin(mv * mw), c_r=_imap(1, d, spec.d_x, 0, 1), c_j=_lin(d), alpha=alpha,
+                    accumulate=xo in seen,
+                )
+                seen.add(xo)
+        if ctx.needs_input_grad[1]:
+            da = (torch.empty if spec.a_covered else torch.zeros)(n, spec.d_a, dtype=torch.float32, device=x.device)
+            seen = set()
+            for xo, mu, ao, mv, oo, mw, d, wo, alpha in spec.instructions:
+                # da[n, v] = sum_{(u,w,k)} x[n,u,k] g[n,w,k] W[u,v,w]
+                _gemm(
+                    n, mv, mu * mw * d, _p(x, xo), _p(weight, wo), _p(da, ao),
+                    a1_r=_lin(spec.d_x), a1_k=_imap(mw, d, d, 0, 1),
+                    a2=_p(g, oo), a2_r=_lin(spec.d_out), a2_k=_imap(mw, d, 0, d, 1),
+                    b_k=_imap(mw, d, mv * mw, 1, 0), b_j=_lin(mw), c_r=_lin(spec.d_a), c_j=_lin(1), alpha=alpha,
+                    accumulate=ao in seen,
+                )
+                seen.add(ao)
+        if ctx.needs_input_grad[2]:
+            dw = torch.empty_like(weight)
+            for xo, mu, ao, mv, oo, mw, d, wo, alpha in spec.instructions:
+                # dW[(u,v), w] = sum_{(n,k)} x[n,u,k] a[n,v] g[n,w,k]
+                _gemm(
+                    mu * mv, mw, n * d, _p(x, xo), _p(g, oo), _p(dw, wo),
+                    a1_r=_imap(1, mv, d, 0, 0), a1_k=_imap(1, d, spec.d_x, 0, 1),
+                    a2=_p(a, ao), a2_r=_imap(1, mv, 0, 0, 1), a2_k=_imap(1, d, spec.d_a, 0, 0),
+                    b_k=_imap(1, d, spec.d_out, 0, 1), b_j=_lin(d), c_r=_lin(mw), c_j=_lin(1), alpha=alpha,
+                )
+        return dx, da, dw, None, (g if ctx.has_base else None)
+
+
+def fctp(x, a, weight, spec: FctpSpec, base: Optional[torch.Tensor] = None):
+    """FullyConnectedTensorProduct(x, a) with scalar `a`; when `base` is given the result is
+    accumulated into it in place (out = base + fctp), saving the separate add."""
+    return _FctpFn.apply(x, a, weight, spec, base)
+
+
+# ------------------------------------------------------------------ Gate
+
+
+@dataclass(frozen=True)
+class GateSpec:
+    d_in: int
+    d_out: int
+    segs: Tuple[Tuple[int, int, int, int, int, int, float], ...]  # in_off,out_off,count,dim,gate_off,act,cst
+
+    def c_array(self):
+        arr = (GateSeg * len(self.segs))()
+        for s, v in zip(arr, self.segs):
+            s.in_off, s.out_off, s.count, s.dim, s.gate_off, s.act, s.cst = v
+        return arr
+
+
+class _GateFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, spec: GateSpec):
+        x = _f32(x, "x")
+        if x.shape[1] != spec.d_in:
+            raise ValueError(f"gate: expected {spec.d_in} columns, got {x.shape[1]}")
+        out = torch.empty(x.shape[0], spec.d_out, dtype=torch.float32, device=x.device)
+        _lib.check(_lib.lib().tfc_gate_fwd(spec.c_array(), len(spec.segs), _ptr(x), x.shape[0], spec.d_in, spec.d_out, _ptr(out), _stream()))
+        ctx.save_for_backward(x)
+        ctx.spec = spec
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        (x,) = ctx.saved_tensors
+        spec = ctx.spec
+        g = _f32(g, "grad_output")
+        dx = torch.empty_like(x)
+        _lib.check(_lib.lib().tfc_gate_bwd(spec.c_array(), len(spec.segs), _ptr(x), _ptr(g), x.shape[0], spec.d_in, spec.d_out, _ptr(dx), _stream()))
+        return dx, None
+
+
+def gate(x, spec: GateSpec):
+    return _GateFn.apply(x, spec)

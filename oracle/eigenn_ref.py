@@ -1,0 +1,513 @@
+"""Oracle (test infrastructure): the reference's composition of the hot path, on CPU.
+
+Unfused, in the reference's op order (o3.Linear -> gather x[edge_index[0]] -> radial
+FullyConnectedNet -> per-path 'uvu' einsum -> scatter_add_ into edge_index[1] ->
+/sqrt(avg_num_neighbors) -> o3.Linear -> + self connection -> Gate -> optional
+residual), autograd backward.  Every class cites the reference file:line it follows
+(paths relative to /root/reference).  The e3nn pieces come from oracle/e3ref.py.
+
+Parity unpinned (oracle/__init__.py).
+"""
+import math
+from typing import Dict, Optional
+
+import torch
+
+from .e3ref import (
+    Activation,
+    FullyConnectedNet,
+    FullyConnectedTensorProduct,
+    Gate,
+    Irrep,
+    Irreps,
+    Linear,
+    TensorProduct,
+    spherical_harmonics,
+)
+
+# eigenn/data/_key.py:14-47
+POSITIONS = "pos"
+NODE_ATTRS = "node_attrs"
+NODE_FEATURES = "node_features"
+EDGE_INDEX = "edge_index"
+EDGE_CELL_SHIFT = "edge_cell_shift"
+EDGE_VECTORS = "edge_vectors"
+EDGE_LENGTH = "edge_lengths"
+EDGE_ATTRS = "edge_attrs"
+EDGE_EMBEDDING = "edge_embedding"
+EDGE_MESSAGE = "edge_message"
+CELL = "cell"
+BATCH = "batch"
+
+_LOG2 = math.log(2.0)
+
+
+def ssp(x):
+    """ShiftedSoftPlus, eigenn/nn/_nequip.py:15-37 (softplus beta=1 threshold=20, minus ln 2)."""
+    return torch.nn.functional.softplus(x, beta=1, threshold=20) - _LOG2
+
+
+# eigenn/nn/utils.py:14-26
+ACTIVATION = {
+    "e": {"ssp": ssp, "silu": torch.nn.functional.silu, "sigmoid": torch.sigmoid},
+    "o": {"abs": torch.abs, "tanh": torch.tanh},
+}
+_ACT_NAME = {id(f): n for d in ACTIVATION.values() for n, f in d.items()}
+
+
+def _fix_irreps_dict(d):
+    """eigenn/data/irreps.py:170-183"""
+    return {k: (None if v is None else Irreps(v)) for k, v in d.items()}
+
+
+class ModuleIrreps:
+    """eigenn/data/irreps.py:17-165 (required-key / type checks and the in->out dict rule)."""
+
+    REQUIRED_KEYS_IRREPS_IN = None
+    REQUIRED_TYPE_IRREPS_IN = None
+
+    def init_irreps(self, irreps_in=None, irreps_out=None):
+        irreps_in = _fix_irreps_dict({} if irreps_in is None else irreps_in)
+        # fix_irreps_in: irreps.py:145-165
+        irreps_in = dict(irreps_in)
+        if POSITIONS in irreps_in and irreps_in[POSITIONS] != Irreps("1x1o"):
+            raise ValueError("Positions must have irreps 1o")
+        irreps_in[POSITIONS] = Irreps("1o")
+        if EDGE_INDEX in irreps_in and irreps_in[EDGE_INDEX] is not None:
+            raise ValueError("Edge indexes must have irreps None")
+        irreps_in[EDGE_INDEX] = None
+        irreps_out = _fix_irreps_dict({} if irreps_out is None else irreps_out)
+        required_keys = list(self.REQUIRED_KEYS_IRREPS_IN or [])
+        required_type = _fix_irreps_dict(self.REQUIRED_TYPE_IRREPS_IN or {})
+        for k in required_keys + list(required_type):
+            if k not in irreps_in:
+                raise ValueError(f"This module {type(self)} requires `{k}` in `irreps_in`.")
+        for k, v in required_type.items():
+            if set(irreps_in[k].ls) != set(v.ls):
+                raise ValueError(f"irreps_in['{k}'] must be of type {v}, got {irreps_in[k]}")
+        self._irreps_in = irreps_in
+        self._irreps_out = dict(irreps_in)
+        self._irreps_out.update(irreps_out)
+
+    @property
+    def irreps_in(self):
+        return self._irreps_in
+
+    @property
+    def irreps_out(self):
+        return self._irreps_out
+
+
+# ----------------------------------------------------------------------------- edge encoders
+
+
+def with_edge_vectors(data, with_lengths=True):
+    """eigenn/nn/_nequip.py:214-266"""
+    if EDGE_VECTORS in data:
+        if with_lengths and EDGE_LENGTH not in data:
+            data[EDGE_LENGTH] = torch.linalg.norm(data[EDGE_VECTORS], dim=-1)
+        return data
+    pos = data[POSITIONS]
+    ei = data[EDGE_INDEX]
+    vec = pos[ei[1]] - pos[ei[0]]
+    if CELL in data:
+        cell = data[CELL].view(-1, 3, 3)
+        shift = data[EDGE_CELL_SHIFT]
+        if cell.shape[0] > 1:
+            batch = data[BATCH]
+            vec = vec + torch.einsum("ni,nij->nj", shift, cell[batch[ei[0]]])
+        else:
+            vec = vec + torch.einsum("ni,ij->nj", shift, cell.squeeze(0))
+    data[EDGE_VECTORS] = vec
+    if with_lengths:
+        data[EDGE_LENGTH] = torch.linalg.norm(vec, dim=-1)
+    return data
+
+
+class PolynomialCutoff(torch.nn.Module):
+    """eigenn/nn/_nequip.py:45-78"""
+
+    def __init__(self, r_max, p=6):
+        super().__init__()
+        self.register_buffer("p", torch.Tensor([p]))
+        self.register_buffer("r_max", torch.Tensor([r_max]))
+
+    def forward(self, x):
+        p, r_max = self.p.to(x.dtype), self.r_max.to(x.dtype)
+        env = (
+            1.0
+            - ((p + 1.0) * (p + 2.0) / 2.0) * torch.pow(x / r_max, p)
+            + p * (p + 2.0) * torch.pow(x / r_max, p + 1.0)
+            - (p * (p + 1.0) / 2) * torch.pow(x / r_max, p + 2.0)
+        )
+        return env * (x < r_max).to(x.dtype)
+
+
+class BesselBasis(torch.nn.Module):
+    """eigenn/nn/_nequip.py:82-128"""
+
+    def __init__(self, r_max, num_basis=8, trainable=True):
+        super().__init__()
+        self.num_basis = num_basis
+        self.r_max = float(r_max)
+        self.prefactor = 2.0 / self.r_max
+        w = torch.linspace(start=1.0, end=num_basis, steps=num_basis) * math.pi
+        if trainable:
+            self.bessel_weights = torch.nn.Parameter(w)
+        else:
+            self.register_buffer("bessel_weights", w)
+
+    def forward(self, x):
+        num = torch.sin(self.bessel_weights * x.unsqueeze(-1) / self.r_max)
+        return self.prefactor * (num / x.unsqueeze(-1))
+
+
+class SphericalHarmonicEdgeAttrs(ModuleIrreps, torch.nn.Module):
+    """eigenn/nn/_nequip.py:132-176"""
+
+    def __init__(self, irreps_edge_sh, edge_sh_normalization="component", edge_sh_normalize=True, irreps_in=None, out_field=EDGE_ATTRS):
+        super().__init__()
+        self.out_field = out_field
+        if isinstance(irreps_edge_sh, int):
+            self.irreps_edge_sh = Irreps.spherical_harmonics(irreps_edge_sh)
+        else:
+            self.irreps_edge_sh = Irreps(irreps_edge_sh)
+        self.init_irreps(irreps_in=irreps_in, irreps_out={out_field: self.irreps_edge_sh})
+        self.normalize = edge_sh_normalize
+        self.normalization = edge_sh_normalization
+
+    def forward(self, data):
+        data = with_edge_vectors(data, with_lengths=False)
+        data[self.out_field] = spherical_harmonics(self.irreps_edge_sh, data[EDGE_VECTORS], self.normalize, self.normalization)
+        return data
+
+
+class RadialBasisEdgeEncoding(ModuleIrreps, torch.nn.Module):
+    """eigenn/nn/_nequip.py:180-210"""
+
+    def __init__(self, basis=BesselBasis, cutoff=PolynomialCutoff, basis_kwargs={}, cutoff_kwargs={}, out_field=EDGE_EMBEDDING, irreps_in=None):
+        super().__init__()
+        self.basis = basis(**basis_kwargs)
+        self.cutoff = cutoff(**cutoff_kwargs)
+        self.out_field = out_field
+        self.init_irreps(irreps_in=irreps_in, irreps_out={out_field: Irreps([(self.basis.num_basis, (0, 1))])})
+
+    def forward(self, data):
+        data = with_edge_vectors(data, with_lengths=True)
+        r = data[EDGE_LENGTH]
+        data[self.out_field] = self.basis(r) * self.cutoff(r)[:, None]
+        return data
+
+
+# ----------------------------------------------------------------------------- nn/utils.py
+
+
+def tp_path_exists(irreps_in1, irreps_in2, ir_out):
+    """eigenn/nn/utils.py:360-369"""
+    irreps_in1 = Irreps(irreps_in1).simplify()
+    irreps_in2 = Irreps(irreps_in2).simplify()
+    ir_out = Irrep(ir_out)
+    for _, ir1 in irreps_in1:
+        for _, ir2 in irreps_in2:
+            if ir_out in ir1 * ir2:
+                return True
+    return False
+
+
+def scatter_add(src, index, dim_size):
+    """eigenn/nn/utils.py:351-357"""
+    out = src.new_zeros(dim_size, src.shape[1])
+    index = index.reshape(-1, 1).expand_as(src)
+    return out.scatter_add_(0, index, src)
+
+
+class ActivationLayer(torch.nn.Module):
+    """eigenn/nn/utils.py:29-168 (gate branch; 'norm' is not on the target models' path)."""
+
+    def __init__(self, tp_irreps_in1, tp_irreps_in2, tp_irreps_out, *, activation_type="gate", activation_scalars=None, activation_gates=None):
+        super().__init__()
+        km = {"e": 1, "o": -1}
+        if activation_scalars is None:
+            activation_scalars = {1: ACTIVATION["e"]["ssp"], -1: ACTIVATION["o"]["tanh"]}
+        else:
+            activation_scalars = {km[k]: ACTIVATION[k][v] for k, v in activation_scalars.items()}
+        if activation_gates is None:
+            activation_gates = {1: ACTIVATION["e"]["ssp"], -1: ACTIVATION["o"]["abs"]}
+        else:
+            activation_gates = {km[k]: ACTIVATION[k][v] for k, v in activation_gates.items()}
+
+        ir_tmp, _, _ = Irreps(tp_irreps_out).sort()
+        tp_irreps_out = ir_tmp.simplify()
+        irreps_scalars = Irreps([(mul, ir) for mul, ir in tp_irreps_out if ir.l == 0 and tp_path_exists(tp_irreps_in1, tp_irreps_in2, ir)])
+        irreps_gated = Irreps([(mul, ir) for mul, ir in tp_irreps_out if ir.l > 0 and tp_path_exists(tp_irreps_in1, tp_irreps_in2, ir)])
+        if activation_type != "gate":
+            raise ValueError(f"Support `activation_type` includes ('gate',) in the oracle, got {activation_type}")
+        if irreps_gated.dim > 0:
+            if tp_path_exists(tp_irreps_in1, tp_irreps_in2, "0e"):
+                ir = "0e"
+            elif tp_path_exists(tp_irreps_in1, tp_irreps_in2, "0o"):
+                ir = "0o"
+            else:
+                raise ValueError("unable to produce gates")
+        else:
+            ir = None
+        irreps_gates = Irreps([(mul, ir) for mul, _ in irreps_gated]).simplify()
+        acts_s = [activation_scalars[ir.p] for _, ir in irreps_scalars]
+        acts_g = [activation_gates[ir.p] for _, ir in irreps_gates]
+        self.activation = Gate(
+            irreps_scalars,
+            acts_s,
+            irreps_gates,
+            acts_g,
+            irreps_gated,
+            keys_scalars=[_ACT_NAME[id(a)] for a in acts_s],
+            keys_gates=[_ACT_NAME[id(a)] for a in acts_g],
+        )
+
+    def forward(self, x):
+        return self.activation(x)
+
+    @property
+    def irreps_in(self):
+        return self.activation.irreps_in
+
+    @property
+    def irreps_out(self):
+        return self.activation.irreps_out
+
+
+class UVUTensorProduct(torch.nn.Module):
+    """eigenn/nn/utils.py:171-279"""
+
+    def __init__(self, irreps_in1, irreps_in2, irreps_out, *, mlp_input_size=None, mlp_hidden_size=8, mlp_num_hidden_layers=1):
+        super().__init__()
+        irreps_in1, irreps_in2, irreps_out = Irreps(irreps_in1), Irreps(irreps_in2), Irreps(irreps_out)
+        irreps_mid, instructions = [], []
+        for i, (mul, ir_in1) in enumerate(irreps_in1):
+            for j, (_, ir_in2) in enumerate(irreps_in2):
+                for ir_out in ir_in1 * ir_in2:
+                    # utils.py:211 also has `or ir_out == Irreps("0e")`: an Irrep never
+                    # equals an Irreps, so that clause is always False.
+                    if ir_out in irreps_out:
+                        k = len(irreps_mid)
+                        irreps_mid.append((mul, ir_out))
+                        instructions.append((i, j, k, "uvu", True))
+        irreps_mid = Irreps(irreps_mid)
+        assert irreps_mid.dim > 0, f"irreps_in1={irreps_in1} times irreps_in2={irreps_in2} produces no instructions in irreps_out={irreps_out}"
+        self.irreps_mid, permutation, _ = irreps_mid.sort()
+        instructions = [(i1, i2, permutation[io], mode, train) for i1, i2, io, mode, train in instructions]
+        self.tp = TensorProduct(irreps_in1, irreps_in2, self.irreps_mid, instructions, internal_weights=False, shared_weights=False)
+        assert mlp_input_size is not None
+        layer_sizes = [mlp_input_size] + mlp_num_hidden_layers * [mlp_hidden_size] + [self.tp.weight_numel]
+        self.weight_nn = FullyConnectedNet(layer_sizes, act=ssp, act_key="ssp")
+
+    def forward(self, data1, data2, data_weight):
+        weight = self.weight_nn(data_weight)
+        return self.tp(data1, data2, weight)
+
+    @property
+    def irreps_out(self):
+        return self.irreps_mid.simplify()
+
+
+# ----------------------------------------------------------------------------- point_conv.py
+
+
+class PointConvMessage(ModuleIrreps, torch.nn.Module):
+    """eigenn/nn/point_conv.py:11-87"""
+
+    REQUIRED_KEYS_IRREPS_IN = [NODE_FEATURES, EDGE_EMBEDDING, EDGE_ATTRS, EDGE_INDEX]
+    REQUIRED_TYPE_IRREPS_IN = {EDGE_EMBEDDING: "0e"}
+
+    def __init__(self, irreps_in, irreps_out, *, fc_num_hidden_layers=1, fc_hidden_size=8):
+        super().__init__()
+        self.init_irreps(irreps_in, irreps_out)
+        nin = self.irreps_in[NODE_FEATURES]
+        nout = self.irreps_out[NODE_FEATURES]
+        self.linear_1 = Linear(nin, nin)
+        self.tp = UVUTensorProduct(
+            nin,
+            self.irreps_in[EDGE_ATTRS],
+            nout,
+            mlp_input_size=self.irreps_in[EDGE_EMBEDDING].dim,
+            mlp_hidden_size=fc_hidden_size,
+            mlp_num_hidden_layers=fc_num_hidden_layers,
+        )
+        self.irreps_out[EDGE_MESSAGE] = self.tp.irreps_out
+
+    def forward(self, data):
+        edge_src, edge_dst = data[EDGE_INDEX]
+        node_feats = self.linear_1(data[NODE_FEATURES])
+        data[EDGE_MESSAGE] = self.tp(node_feats[edge_src], data[EDGE_ATTRS], data[EDGE_EMBEDDING])
+        return data
+
+
+class PointConvUpdate(ModuleIrreps, torch.nn.Module):
+    """eigenn/nn/point_conv.py:90-194"""
+
+    REQUIRED_KEYS_IRREPS_IN = [NODE_FEATURES, NODE_ATTRS, EDGE_MESSAGE, EDGE_INDEX]
+
+    def __init__(self, irreps_in, irreps_out, *, use_self_connection=True, avg_num_neighbors=None):
+        super().__init__()
+        self.avg_num_neighbors = avg_num_neighbors
+        self.init_irreps(irreps_in, irreps_out)
+        nin = self.irreps_in[NODE_FEATURES]
+        nout = self.irreps_out[NODE_FEATURES]
+        self.linear_2 = Linear(self.irreps_in[EDGE_MESSAGE], nout)
+        if use_self_connection:
+            self.self_connection = FullyConnectedTensorProduct(nin, self.irreps_in[NODE_ATTRS], nout)
+        else:
+            self.self_connection = None
+
+    def forward(self, data):
+        node_feats = data[NODE_FEATURES]
+        edge_src, edge_dst = data[EDGE_INDEX]
+        msg = scatter_add(data[EDGE_MESSAGE], edge_dst, dim_size=len(node_feats))
+        if self.avg_num_neighbors is not None:
+            msg = msg / self.avg_num_neighbors**0.5
+        msg = self.linear_2(msg)
+        if self.self_connection is not None:
+            node_feats = msg + self.self_connection(node_feats, data[NODE_ATTRS])
+        else:
+            node_feats = msg
+        data[NODE_FEATURES] = node_feats
+        return data
+
+
+class PointConvMessagePassing(ModuleIrreps, torch.nn.Module):
+    """eigenn/nn/point_conv.py:197-347"""
+
+    def __init__(
+        self,
+        irreps_in,
+        conv_layer_irreps,
+        message=PointConvMessage,
+        update=PointConvUpdate,
+        message_kwargs: Optional[Dict] = None,
+        update_kwargs: Optional[Dict] = None,
+        activation_type="gate",
+        activation_scalars=None,
+        activation_gates=None,
+        use_resnet=True,
+    ):
+        super().__init__()
+        message_kwargs = {} if message_kwargs is None else dict(message_kwargs)
+        update_kwargs = {} if update_kwargs is None else dict(update_kwargs)
+        self.init_irreps(irreps_in)
+        edge_attrs_irreps = self.irreps_in[EDGE_ATTRS]
+        nin = self.irreps_in[NODE_FEATURES]
+        self.equivariant_nonlinear = ActivationLayer(
+            tp_irreps_in1=nin,
+            tp_irreps_in2=edge_attrs_irreps,
+            tp_irreps_out=conv_layer_irreps,
+            activation_type=activation_type,
+            activation_scalars=activation_scalars,
+            activation_gates=activation_gates,
+        )
+        before = self.equivariant_nonlinear.irreps_in
+        after = self.equivariant_nonlinear.irreps_out
+        message_kwargs.pop("irreps_in", None)
+        message_kwargs.pop("irreps_out", None)
+        self.message_fn = message(irreps_in=self.irreps_in, irreps_out={NODE_FEATURES: before}, **message_kwargs)
+        upd_in = dict(self.irreps_in)
+        upd_in[EDGE_MESSAGE] = self.message_fn.irreps_out[EDGE_MESSAGE]
+        update_kwargs.pop("irreps_in", None)
+        update_kwargs.pop("irreps_out", None)
+        self.update_fn = update(irreps_in=upd_in, irreps_out={NODE_FEATURES: before}, **update_kwargs)
+        self.use_resnet = bool(use_resnet and after == nin)
+        self.irreps_out.update(self.update_fn.irreps_out)
+        self.irreps_out[NODE_FEATURES] = after
+
+    def forward(self, data):
+        old_x = data[NODE_FEATURES]
+        data = self.message_fn(data)
+        data = self.update_fn(data)
+        x = self.equivariant_nonlinear(data[NODE_FEATURES])
+        data[NODE_FEATURES] = old_x + x if self.use_resnet else x
+        return data
+
+
+class PointConv(ModuleIrreps, torch.nn.Module):
+    """Legacy layer, eigenn/nn/point_conv.py:351-491 (no activation, explicit irreps_out)."""
+
+    REQUIRED_KEYS_IRREPS_IN = [NODE_FEATURES, NODE_ATTRS, EDGE_EMBEDDING, EDGE_ATTRS, EDGE_INDEX]
+    REQUIRED_TYPE_IRREPS_IN = {EDGE_EMBEDDING: "0e"}
+
+    def __init__(self, irreps_in, irreps_out, *, fc_num_hidden_layers=1, fc_hidden_size=8, use_self_connection=True, avg_num_neighbors=None):
+        super().__init__()
+        self.avg_num_neighbors = avg_num_neighbors
+        self.init_irreps(irreps_in, irreps_out)
+        nin = self.irreps_in[NODE_FEATURES]
+        nout = self.irreps_out[NODE_FEATURES]
+        self.linear_1 = Linear(nin, nin)
+        self.tp = UVUTensorProduct(
+            nin,
+            self.irreps_in[EDGE_ATTRS],
+            nout,
+            mlp_input_size=self.irreps_in[EDGE_EMBEDDING].dim,
+            mlp_hidden_size=fc_hidden_size,
+            mlp_num_hidden_layers=fc_num_hidden_layers,
+        )
+        self.linear_2 = Linear(self.tp.irreps_out, nout)
+        self.self_connection = FullyConnectedTensorProduct(nin, self.irreps_in[NODE_ATTRS], nout) if use_self_connection else None
+
+    def forward(self, data):
+        data = data.copy()
+        x_in = data[NODE_FEATURES]
+        edge_src, edge_dst = data[EDGE_INDEX]
+        x = self.linear_1(x_in)
+        msg_e = self.tp(x[edge_src], data[EDGE_ATTRS], data[EDGE_EMBEDDING])
+        msg = scatter_add(msg_e, edge_dst, dim_size=len(x))
+        if self.avg_num_neighbors is not None:
+            msg = msg / self.avg_num_neighbors**0.5
+        msg = self.linear_2(msg)
+        if self.self_connection is not None:
+            x = msg + self.self_connection(x_in, data[NODE_ATTRS])
+        else:
+            x = msg
+        data[NODE_FEATURES] = x
+        return data
+
+
+# ----------------------------------------------------------------------------- neighbour list
+
+
+def neighbor_list_bruteforce(pos, cell, pbc, r_max):
+    """Set semantics of ase.neighborlist.primitive_neighbor_list("ijS", ...) as used at
+    eigenn/data/data.py:480-502 (strict `<` cutoff in fp64, i==j images kept, the
+    (i==j, S==0) self edge dropped).  Brute-force enumeration; canonical order
+    (i, j, Sx, Sy, Sz).  Returns numpy int64 arrays (edge_index [2,E], shifts [E,3])."""
+    import numpy as np
+
+    pos = np.asarray(pos, dtype=np.float64)
+    cell = np.asarray(cell, dtype=np.float64).reshape(3, 3)
+    pbc = [bool(b) for b in (pbc if hasattr(pbc, "__len__") else (pbc,) * 3)]
+    n = len(pos)
+    # number of images needed along each axis: r_max / (distance between cell faces)
+    vol = abs(np.linalg.det(cell))
+    reps = []
+    for a in range(3):
+        if not pbc[a]:
+            reps.append(0)
+            continue
+        b, c = cell[(a + 1) % 3], cell[(a + 2) % 3]
+        h = vol / np.linalg.norm(np.cross(b, c))
+        reps.append(int(math.ceil(r_max / h)) + 1)
+    out = []
+    frac_span = [range(-r, r + 1) for r in reps]
+    import itertools
+
+    for S in itertools.product(*frac_span):
+        Sv = np.asarray(S, dtype=np.float64) @ cell
+        d = pos[None, :, :] - pos[:, None, :] + Sv[None, None, :]
+        dist = np.sqrt((d * d).sum(-1))
+        ii, jj = np.nonzero(dist < r_max)
+        for i, j in zip(ii, jj):
+            if i == j and S == (0, 0, 0):
+                continue
+            out.append((int(i), int(j), S[0], S[1], S[2]))
+    out.sort()
+    if not out:
+        raise ValueError("After eliminating self edges, no edges remain in this system.")
+    arr = np.asarray(out, dtype=np.int64)
+    return arr[:, :2].T.copy(), arr[:, 2:].copy()

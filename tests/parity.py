@@ -1,0 +1,178 @@
+"""Parity harness: the HIP path (matten_amd, through the C ABI) against the CPU oracle
+(oracle/, restating the reference) on the same seeded inputs and the same weights.
+
+Used by the -m gpu tests, by __graft_entry__.smoke() and by bench.py's correctness guard.
+The model under test is the hot path end to end: species embedding (plain torch lookup on
+both sides; eigenn/nn/embedding.py is out of scope) -> SphericalHarmonicEdgeAttrs ->
+RadialBasisEdgeEncoding -> L x PointConvMessagePassing -> a fixed random linear read-out to a
+per-graph "energy"; compared: node features after the last layer, energies, forces
+(-dE/dpos through every backward kernel) and every parameter gradient.
+
+Tolerance (fp32, stated by BASELINE.json's north_star): 1e-5 relative.  "Relative" is taken
+against the largest magnitude of the compared tensor (max-norm), which is what a sum of
+O(30) rounded fp32 products can meet; the oracle is evaluated in fp64 as the reference value
+and in fp32 to show what the reference's own arithmetic achieves on the same input.
+"""
+from __future__ import annotations
+
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+CONFIGS = {
+    # name: (emb, sh lmax, conv irreps, layers, mlp hidden, mlp hidden layers, crystal n, a, graphs)
+    "smoke": dict(emb=8, lmax=2, irreps="8x0o+8x0e+4x1o+4x1e+2x2o+2x2e", layers=2, hidden=16, nh=2, n=2, a=2.6, graphs=2),
+    "minimal": dict(emb=32, lmax=2, irreps="32x0o+32x0e+16x1o+16x1e+8x2o+8x2e", layers=3, hidden=64, nh=2, n=2, a=2.55, graphs=3),
+    "lmax3": dict(emb=16, lmax=3, irreps="16x0o+16x0e+16x1o+16x1e+8x2o+8x2e+4x3o+4x3e", layers=3, hidden=32, nh=1, n=2, a=2.7, graphs=2),
+    "c3": dict(emb=64, lmax=2, irreps="64x0o+64x0e+64x1o+64x1e+64x2o+64x2e", layers=3, hidden=64, nh=2, n=3, a=2.5, graphs=2),
+    "c4": dict(emb=128, lmax=3, irreps="128x0o+128x0e+128x1o+128x1e+128x2o+128x2e+128x3o+128x3e", layers=2, hidden=64, nh=2, n=2, a=2.6, graphs=1),
+}
+R_CUT = 5.0
+AVG_NEIGH = 28.0
+
+
+def make_batch(cfg, seed0=1000):
+    from matten_amd.data.crystal import synthetic_batch
+
+    batch, _ = synthetic_batch(cfg["n"], cfg["a"], cfg["graphs"], seed0=seed0, r_cut=R_CUT)
+    return batch
+
+
+def species_index(z):
+    table = {1: 0, 6: 1, 8: 2, 14: 3}
+    return torch.tensor([table[int(v)] for v in z.tolist()], dtype=torch.long)
+
+
+class Stack(torch.nn.Module):
+    """embedding -> SH -> radial -> conv layers, built from either implementation."""
+
+    def __init__(self, impl, cfg):
+        super().__init__()
+        if impl == "oracle":
+            from oracle import eigenn_ref as M
+
+            Irreps = M.Irreps
+        else:
+            import matten_amd.nn as M
+            from matten_amd.irreps import Irreps
+        self.K = __import__("matten_amd.keys", fromlist=["x"])
+        K = self.K
+        emb = cfg["emb"]
+        self.embedding = torch.nn.Embedding(4, emb)
+        irreps = {K.NODE_FEATURES: f"{emb}x0e", K.NODE_ATTRS: f"{emb}x0e", K.EDGE_INDEX: None, K.POSITIONS: "1o"}
+        self.spharm_edges = M.SphericalHarmonicEdgeAttrs(irreps_edge_sh=cfg["lmax"], irreps_in=irreps)
+        self.radial_basis = M.RadialBasisEdgeEncoding(
+            basis_kwargs={"num_basis": 8, "r_max": R_CUT}, cutoff_kwargs={"r_max": R_CUT}, irreps_in=self.spharm_edges.irreps_out
+        )
+        cur = self.radial_basis.irreps_out
+        self.convs = torch.nn.ModuleList()
+        for _ in range(cfg["layers"]):
+            layer = M.PointConvMessagePassing(
+                irreps_in=cur,
+                conv_layer_irreps=cfg["irreps"],
+                message_kwargs={"fc_num_hidden_layers": cfg["nh"], "fc_hidden_size": cfg["hidden"]},
+                update_kwargs={"use_self_connection": True, "avg_num_neighbors": AVG_NEIGH},
+                activation_type="gate",
+                use_resnet=True,
+            )
+            self.convs.append(layer)
+            cur = layer.irreps_out
+        self.d_out = Irreps(cur[K.NODE_FEATURES]).dim
+        g = torch.Generator().manual_seed(7)
+        self.register_buffer("readout", torch.randn(self.d_out, generator=g) / self.d_out**0.5)
+
+    def forward(self, batch):
+        K = self.K
+        data = dict(batch)
+        x = self.embedding(data["species_index"])
+        data[K.NODE_FEATURES] = x
+        data[K.NODE_ATTRS] = x
+        data = self.spharm_edges(data)
+        data = self.radial_basis(data)
+        for layer in self.convs:
+            data = layer(data)
+        feats = data[K.NODE_FEATURES]
+        per_atom = feats @ self.readout.to(feats.dtype)
+        n_graphs = int(data[K.BATCH].max().item()) + 1
+        energy = torch.zeros(n_graphs, dtype=feats.dtype, device=feats.device).index_add_(0, data[K.BATCH], per_atom)
+        return feats, energy, data
+
+
+def _prep(batch, device, dtype):
+    K = __import__("matten_amd.keys", fromlist=["x"])
+    out = {}
+    for k, v in batch.items():
+        if v.is_floating_point():
+            v = v.to(dtype)
+        out[k] = v.to(device)
+    out["species_index"] = species_index(batch[K.ATOMIC_NUMBERS]).to(device)
+    out[K.POSITIONS] = out[K.POSITIONS].clone().requires_grad_(True)
+    return out
+
+
+def run_stack(model, batch, device, dtype):
+    K = __import__("matten_amd.keys", fromlist=["x"])
+    model = model.to(device=device, dtype=dtype)
+    b = _prep(batch, device, dtype)
+    feats, energy, data = model(b)
+    params = [p for p in model.parameters()]
+    grads = torch.autograd.grad(energy.sum(), [b[K.POSITIONS]] + params, allow_unused=True)
+    res = {"feats": feats.detach(), "energy": energy.detach(), "forces": -grads[0].detach()}
+    for (name, _), g in zip(model.named_parameters(), grads[1:]):
+        res["grad:" + name] = None if g is None else g.detach()
+    res["edge_attrs"] = data[K.EDGE_ATTRS].detach()
+    res["edge_embedding"] = data[K.EDGE_EMBEDDING].detach()
+    return res
+
+
+def rel_err(a, ref):
+    a = a.detach().double().cpu()
+    ref = ref.detach().double().cpu()
+    scale = ref.abs().max().item()
+    if scale == 0:
+        return (a - ref).abs().max().item()
+    return (a - ref).abs().max().item() / scale
+
+
+def run_layer_parity(config="smoke", device="cuda:0", verbose=False, tol=1e-5, seed=35):
+    cfg = CONFIGS[config] if isinstance(config, str) else config
+    torch.manual_seed(seed)
+    batch = make_batch(cfg)
+    oracle = Stack("oracle", cfg)
+    state = {k: v.clone() for k, v in oracle.state_dict().items()}
+    ref64 = run_stack(oracle, batch, "cpu", torch.float64)
+    oracle.load_state_dict(state)
+    o32 = Stack("oracle", cfg)
+    o32.load_state_dict(state)
+    ref32 = run_stack(o32, batch, "cpu", torch.float32)
+    prod = Stack("hip", cfg)
+    prod.load_state_dict(state, strict=True)  # reference-compatible parameter names
+    got = run_stack(prod, batch, device, torch.float32)
+    torch.cuda.synchronize()
+    report = {}
+    worst = 0.0
+    for k, r in ref64.items():
+        g = got[k]
+        if r is None or g is None:
+            assert (r is None) == (g is None), f"{k}: gradient present on one side only"
+            continue
+        e = rel_err(g, r)
+        e32 = rel_err(ref32[k], r)
+        report[k] = (e, e32)
+        worst = max(worst, e)
+        if verbose:
+            print(f"  {k:60s} hip-vs-fp64 {e:9.2e}   oracle32-vs-fp64 {e32:9.2e}")
+    n_edges = int(batch["edge_index"].shape[1])
+    return {"ok": worst <= tol, "worst": worst, "tol": tol, "n_edges": n_edges, "n_nodes": int(batch["pos"].shape[0]), "report": report}
+
+
+if __name__ == "__main__":
+    name = sys.argv[1] if len(sys.argv) > 1 else "smoke"
+    out = run_layer_parity(name, verbose=True)
+    print({k: v for k, v in out.items() if k != "report"})

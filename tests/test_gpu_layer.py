@@ -1,0 +1,32 @@
+"""-m gpu: the whole hot path (edge encoders + stacked PointConvMessagePassing layers) through
+the C ABI against the CPU oracle: node features, energies, forces, every parameter gradient.
+Tolerance 1e-5 relative (fp32, max-norm), as BASELINE.json's north_star states."""
+import pytest
+import torch
+
+from tests.parity import CONFIGS, run_layer_parity
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("config", ["smoke", "minimal", "lmax3", "c3", "c4"])
+def test_stack_parity(device, config):
+    out = run_layer_parity(config, device=str(device), verbose=True)
+    bad = {k: v for k, v in out["report"].items() if v[0] > out["tol"]}
+    assert out["ok"], f"worst {out['worst']:.2e} > {out['tol']:.0e}: {bad}"
+
+
+def test_native_library_is_loaded(device):
+    """The product path has no fallback: the HIP library must be the thing that ran."""
+    from matten_amd import _lib
+
+    assert _lib.lib().tfc_version() >= 100
+    with open("/proc/self/maps") as f:
+        assert "libtfc.so" in f.read()
+
+
+def test_cpu_tensors_are_refused(device):
+    from matten_amd.nn.e3 import Linear
+
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        Linear("4x0e", "4x0e")(torch.randn(3, 4))

@@ -1,0 +1,345 @@
+"""-m gpu: every libtfc kernel, called through the C ABI (ctypes), against the CPU oracle on
+the same seeded inputs.  Tolerance: 1e-5 relative (fp32) to the tensor's max-norm, as
+BASELINE.json's north_star states; integer orderings must be bit-exact."""
+import math
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-5
+
+
+def rel(a, ref):
+    a, ref = a.detach().double().cpu(), ref.detach().double().cpu()
+    s = ref.abs().max().item()
+    return (a - ref).abs().max().item() / (s if s > 0 else 1.0)
+
+
+def random_graph(n_nodes, n_edges, seed, device):
+    g = torch.Generator().manual_seed(seed)
+    ei = torch.randint(0, n_nodes, (2, n_edges), generator=g)
+    return ei.to(device)
+
+
+# --------------------------------------------------------------------------------------- csr
+@pytest.mark.parametrize("n_nodes,n_edges", [(1, 1), (7, 0), (50, 400), (3000, 90000), (5, 3000)])
+def test_csr_build_bit_exact(device, n_nodes, n_edges):
+    from matten_amd import ops
+
+    ei = random_graph(n_nodes, n_edges, 1, device)
+    o = ops.EdgeOrdering(ei, n_nodes)
+    o.validate()
+    for key_row, (rp, eid, nbr) in ((1, o.by_dst), (0, o.by_src)):
+        key = ei[key_row].cpu()
+        other = ei[1 - key_row].cpu()
+        order = torch.sort(key, stable=True).indices
+        counts = torch.bincount(key, minlength=n_nodes)
+        rp_ref = torch.cat([torch.zeros(1, dtype=torch.long), counts.cumsum(0)])
+        assert torch.equal(rp.cpu().long(), rp_ref)
+        if n_edges:
+            assert torch.equal(eid.cpu().long()[:n_edges], order)
+            assert torch.equal(nbr.cpu().long()[:n_edges], other[order])
+
+
+def test_csr_flags_bad_index(device):
+    from matten_amd import ops
+
+    ei = torch.tensor([[0, 1, 5], [1, 0, 1]], device=device)
+    o = ops.EdgeOrdering(ei, 3)
+    with pytest.raises(IndexError):
+        o.validate()
+
+
+# --------------------------------------------------------------------------------------- gemm
+@pytest.mark.parametrize("m,n,k", [(1, 1, 1), (100, 70, 37), (64, 64, 16), (300, 130, 8), (1000, 1728, 64), (64, 200, 5000), (4096, 64, 333)])
+@pytest.mark.parametrize("layout", ["nn", "nt", "tn"])
+def test_gemm_plain(device, m, n, k, layout):
+    from matten_amd import ops
+
+    g = torch.Generator().manual_seed(m * 7 + n * 3 + k)
+    A = torch.randn(m, k, generator=g)
+    B = torch.randn(k, n, generator=g)
+    ref = (A.double() @ B.double()) * 0.37
+    if layout == "nn":
+        a, b = A.contiguous().to(device), B.contiguous().to(device)
+        a_r, a_k, b_k, b_j = ops._lin(k), ops._lin(1), ops._lin(n), ops._lin(1)
+    elif layout == "nt":
+        a, b = A.contiguous().to(device), B.t().contiguous().to(device)
+        a_r, a_k, b_k, b_j = ops._lin(k), ops._lin(1), ops._lin(1), ops._lin(k)
+    else:
+        a, b = A.t().contiguous().to(device), B.contiguous().to(device)
+        a_r, a_k, b_k, b_j = ops._lin(1), ops._lin(m), ops._lin(n), ops._lin(1)
+    c = torch.full((m, n), float("nan"), device=device)
+    ops._gemm(m, n, k, ops._p(a), ops._p(b), ops._p(c), a_r, a_k, b_k, b_j, ops._lin(n), ops._lin(1), alpha=0.37)
+    assert rel(c, ref) < TOL
+    # accumulate on top
+    ops._gemm(m, n, k, ops._p(a), ops._p(b), ops._p(c), a_r, a_k, b_k, b_j, ops._lin(n), ops._lin(1), alpha=0.37, accumulate=True)
+    assert rel(c, 2 * ref) < TOL
+
+
+# --------------------------------------------------------------------------------------- e3 blocks
+def _pair_state(oracle_mod, hip_mod):
+    hip_mod.load_state_dict({k: v.float() for k, v in oracle_mod.state_dict().items()}, strict=True)
+
+
+@pytest.mark.parametrize(
+    "irreps_in,irreps_out",
+    [
+        ("32x0e", "32x0e"),
+        ("32x0e+16x1o+8x2e", "32x0e+16x1o+8x2e"),
+        ("56x0e+72x1o+24x1e+24x2o+64x2e", "80x0e+16x1o+16x1e+8x2o+8x2e"),
+        ("4x1e+2x0e", "8x1e+4x0e"),
+        ("8x0e+8x0e+3x1o", "5x0e+2x1o+2x1o+3x2e"),
+        ("130x0e+70x3o", "65x0e+100x3o"),
+    ],
+)
+def test_linear_vs_oracle(device, irreps_in, irreps_out):
+    from matten_amd.nn.e3 import Linear
+    from oracle import e3ref
+
+    torch.manual_seed(0)
+    o = e3ref.Linear(irreps_in, irreps_out).double()
+    h = Linear(irreps_in, irreps_out)
+    _pair_state(o, h)
+    h = h.to(device)
+    n = 77
+    x = torch.randn(n, o.irreps_in.dim, dtype=torch.float64, requires_grad=True)
+    xg = x.detach().float().to(device).requires_grad_(True)
+    y, yg = o(x), h(xg)
+    assert rel(yg, y) < TOL
+    go = torch.randn_like(y)
+    gx, gw = torch.autograd.grad(y, [x, o.weight], go)
+    gxg, gwg = torch.autograd.grad(yg, [xg, h.weight], go.float().to(device))
+    assert rel(gxg, gx) < TOL
+    assert rel(gwg, gw) < TOL
+
+
+@pytest.mark.parametrize(
+    "in1,in2,out",
+    [
+        ("32x0e", "32x0e", "56x0e+16x1o+8x2e"),
+        ("32x0e+16x1o+8x2e", "32x0e", "80x0e+16x1o+16x1e+8x2o+8x2e"),
+        ("64x0e+64x1o+64x1e+64x2o+64x2e", "64x0e", "64x0o+256x0e+64x1o+64x1e+64x2o+64x2e"),
+        ("5x0e+3x1o+2x3o", "7x0e", "4x0e+6x1o+3x3o"),
+    ],
+)
+def test_fctp_vs_oracle(device, in1, in2, out):
+    from matten_amd.nn.e3 import FullyConnectedTensorProduct
+    from oracle import e3ref
+
+    torch.manual_seed(1)
+    o = e3ref.FullyConnectedTensorProduct(in1, in2, out).double()
+    h = FullyConnectedTensorProduct(in1, in2, out)
+    _pair_state(o, h)
+    h = h.to(device)
+    n = 41
+    x = torch.randn(n, o.irreps_in1.dim, dtype=torch.float64, requires_grad=True)
+    a = torch.randn(n, o.irreps_in2.dim, dtype=torch.float64, requires_grad=True)
+    base = torch.randn(n, o.irreps_out.dim, dtype=torch.float64, requires_grad=True)
+    xg, ag, bg = (t.detach().float().to(device).requires_grad_(True) for t in (x, a, base))
+    y = base + o(x, a)
+    yg = h(xg, ag, base=bg * 1.0)
+    assert rel(yg, y) < TOL
+    go = torch.randn_like(y)
+    ref = torch.autograd.grad(y, [x, a, o.weight, base], go)
+    got = torch.autograd.grad(yg, [xg, ag, h.weight, bg], go.float().to(device))
+    for r, g_ in zip(ref, got):
+        assert rel(g_, r) < TOL
+    # without base
+    y2, y2g = o(x, a), h(xg, ag)
+    assert rel(y2g, y2) < TOL
+
+
+@pytest.mark.parametrize("hs", [[8, 64, 64, 96], [8, 64, 384], [4, 8, 24], [8, 64, 64, 1728]])
+def test_radial_mlp_vs_oracle(device, hs):
+    from matten_amd.nn.e3 import FullyConnectedNet
+    from oracle import e3ref
+    from oracle.eigenn_ref import ssp
+
+    torch.manual_seed(2)
+    o = e3ref.FullyConnectedNet(hs, act=ssp, act_key="ssp").double()
+    h = FullyConnectedNet(hs, act="ssp")
+    _pair_state(o, h)
+    h = h.to(device)
+    e = 1234
+    x = torch.randn(e, hs[0], dtype=torch.float64, requires_grad=True)
+    xg = x.detach().float().to(device).requires_grad_(True)
+    y, yg = o(x), h(xg)
+    assert rel(yg, y) < TOL
+    go = torch.randn_like(y)
+    ref = torch.autograd.grad(y, [x] + list(o.parameters()), go)
+    got = torch.autograd.grad(yg, [xg] + list(h.parameters()), go.float().to(device))
+    for r, g_ in zip(ref, got):
+        assert rel(g_, r) < TOL
+
+
+@pytest.mark.parametrize(
+    "scalars,acts_s,gates,acts_g,gated",
+    [
+        ("32x0e", ["ssp"], "24x0e", ["ssp"], "16x1o+8x2e"),
+        ("32x0o+32x0e", ["tanh", "ssp"], "48x0e", ["ssp"], "16x1o+16x1e+8x2o+8x2e"),
+        ("8x0o", ["tanh"], "6x0o", ["abs"], "4x1o+2x2e"),
+        ("5x0e", ["silu"], "", [], ""),
+        ("3x0e", ["sigmoid"], "4x0o", ["tanh"], "4x1e"),
+    ],
+)
+def test_gate_vs_oracle(device, scalars, acts_s, gates, acts_g, gated):
+    from matten_amd.nn.e3 import Gate
+    from oracle import e3ref
+    from oracle.eigenn_ref import ACTIVATION
+
+    fn = {**ACTIVATION["e"], **ACTIVATION["o"]}
+    o = e3ref.Gate(scalars, [fn[a] for a in acts_s], gates, [fn[a] for a in acts_g], gated, keys_scalars=acts_s, keys_gates=acts_g)
+    h = Gate(scalars, acts_s, gates, acts_g, gated)
+    assert str(h.irreps_in) == str(o.irreps_in) and str(h.irreps_out) == str(o.irreps_out)
+    torch.manual_seed(3)
+    x = torch.randn(93, o.irreps_in.dim, dtype=torch.float64, requires_grad=True)
+    xg = x.detach().float().to(device).requires_grad_(True)
+    y, yg = o(x), h(xg)
+    assert rel(yg, y) < TOL
+    go = torch.randn_like(y)
+    (gx,) = torch.autograd.grad(y, [x], go)
+    (gxg,) = torch.autograd.grad(yg, [xg], go.float().to(device))
+    assert rel(gxg, gx) < TOL
+
+
+# --------------------------------------------------------------------------------------- conv
+@pytest.mark.parametrize(
+    "in1,sh,out,n_nodes,n_edges",
+    [
+        ("8x0e", "0e+1o+2e", "8x0o+8x0e+4x1o+4x1e+2x2o+2x2e", 10, 120),
+        ("32x0e+16x1o+8x2e", "0e+1o+2e", "32x0o+32x0e+16x1o+16x1e+8x2o+8x2e", 30, 500),
+        ("32x0e+16x1o+16x1e+8x2o+8x2e", "0e+1o+2e", "32x0o+32x0e+16x1o+16x1e+8x2o+8x2e", 30, 700),
+        ("64x0e+64x1o+64x1e+64x2o+64x2e", "0e+1o+2e", "64x0o+64x0e+64x1o+64x1e+64x2o+64x2e", 20, 300),
+        ("96x0e+70x1o+130x2e", "0e+1o+2e", "96x0e+70x1o+130x2e+70x1e", 9, 100),
+        ("16x0e+16x1o+8x2e+4x3o", "0e+1o+2e+3o", "16x0o+16x0e+16x1o+16x1e+8x2o+8x2e+4x3o+4x3e", 12, 200),
+        ("8x0e+8x3o+8x3e", "0e+1o+2e+3o", "8x0e+8x1o+8x2e+8x3o+8x3e", 6, 1),
+    ],
+)
+@pytest.mark.parametrize("need_dy", [True, False])
+def test_conv_vs_oracle(device, in1, sh, out, n_nodes, n_edges, need_dy):
+    """gather -> uvu tensor product -> scatter_add -> scale, forward and all three gradients."""
+    from matten_amd import ops
+    from matten_amd.nn.utils import UVUTensorProduct
+    from oracle import eigenn_ref as R
+
+    torch.manual_seed(4)
+    o = R.UVUTensorProduct(in1, sh, out, mlp_input_size=4, mlp_hidden_size=8, mlp_num_hidden_layers=1)
+    h = UVUTensorProduct(in1, sh, out, mlp_input_size=4, mlp_hidden_size=8, mlp_num_hidden_layers=1)
+    assert str(h.irreps_out) == str(o.irreps_out)
+    ei = random_graph(n_nodes, n_edges, 5, "cpu")
+    x = torch.randn(n_nodes, o.tp.irreps_in1.dim, dtype=torch.float64, requires_grad=True)
+    v = torch.randn(n_edges, 3, dtype=torch.float64)
+    y = R.spherical_harmonics(sh, v, True, "component").requires_grad_(True)
+    w = torch.randn(n_edges, o.tp.weight_numel, dtype=torch.float64, requires_grad=True)
+    scale = 0.41
+    msg = o.tp(x[ei[0]], y, w)
+    ref = R.scatter_add(msg, ei[1], n_nodes) * scale
+    go = torch.randn_like(ref)
+    gref = torch.autograd.grad(ref, [x, y, w], go, retain_graph=True)
+
+    xg, yg, wg = (t.detach().float().to(device).requires_grad_(True) for t in (x, y, w))
+    if not need_dy:
+        yg = yg.detach()
+    ordering = ops.EdgeOrdering(ei.to(device), n_nodes)
+    got = h.tp(xg, yg, wg, ordering, scale)
+    assert rel(got, ref) < TOL
+    ins = [xg, yg, wg] if need_dy else [xg, wg]
+    ggot = torch.autograd.grad(got, ins, go.float().to(device))
+    refs = gref if need_dy else (gref[0], gref[2])
+    for r, g_ in zip(refs, ggot):
+        assert rel(g_, r) < TOL
+    # the unfused per-edge route gives the reference's EDGE_MESSAGE tensor
+    per_edge = h.tp(xg, yg, wg, ordering, 1.0, per_edge=True)
+    assert rel(per_edge, msg) < TOL
+    gm = torch.randn_like(msg)
+    gref2 = torch.autograd.grad(msg, [x, w], gm)
+    ggot2 = torch.autograd.grad(per_edge, [xg, wg], gm.float().to(device))
+    for r, g_ in zip(gref2, ggot2):
+        assert rel(g_, r) < TOL
+
+
+def test_conv_deterministic(device):
+    from matten_amd import ops
+    from matten_amd.nn.utils import UVUTensorProduct
+
+    torch.manual_seed(6)
+    h = UVUTensorProduct("32x0e+16x1o+8x2e", "0e+1o+2e", "32x0o+32x0e+16x1o+16x1e+8x2o+8x2e", mlp_input_size=4)
+    n, e = 40, 2000
+    ei = random_graph(n, e, 7, device)
+    x = torch.randn(n, 120, device=device)
+    y = torch.randn(e, 9, device=device)
+    w = torch.randn(e, h.tp.weight_numel, device=device)
+    outs = [h.tp(x, y, w, ops.EdgeOrdering(ei, n), 1.0) for _ in range(3)]
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+
+
+def test_scatter_add_route(device):
+    from matten_amd.nn.utils import scatter_add
+
+    torch.manual_seed(8)
+    src = torch.randn(500, 37, dtype=torch.float64, requires_grad=True)
+    idx = torch.randint(0, 20, (500,))
+    ref = torch.zeros(25, 37, dtype=torch.float64).index_add_(0, idx, src)
+    sg = src.detach().float().to(device).requires_grad_(True)
+    got = scatter_add(sg, idx.to(device), 25)
+    assert rel(got, ref) < TOL
+    go = torch.randn_like(ref)
+    (gr,) = torch.autograd.grad(ref, [src], go)
+    (gg,) = torch.autograd.grad(got, [sg], go.float().to(device))
+    assert rel(gg, gr) < TOL
+
+
+# --------------------------------------------------------------------------------------- edge encoders
+@pytest.mark.parametrize("lmax", [0, 1, 2, 3])
+@pytest.mark.parametrize("batched_cell", [True, False])
+def test_edge_encoders_vs_oracle(device, lmax, batched_cell):
+    import matten_amd.nn as H
+    from matten_amd import keys as K
+    from matten_amd.data.crystal import synthetic_batch
+    from oracle import eigenn_ref as R
+
+    batch, _ = synthetic_batch(2, 2.6, 2 if batched_cell else 1, seed0=77)
+    torch.manual_seed(9)
+
+    def run(M, dev, dtype):
+        data = {k: (v.to(dtype) if v.is_floating_point() else v).to(dev) for k, v in batch.items()}
+        data[K.POSITIONS] = data[K.POSITIONS].clone().requires_grad_(True)
+        sh = M.SphericalHarmonicEdgeAttrs(irreps_edge_sh=lmax)
+        rb = M.RadialBasisEdgeEncoding(basis_kwargs={"num_basis": 8, "r_max": 5.0}, cutoff_kwargs={"r_max": 5.0}).to(dev, dtype)
+        data = rb(sh(data))
+        g = torch.Generator().manual_seed(10)
+        ga = torch.randn(data[K.EDGE_ATTRS].shape, generator=g, dtype=torch.float64).to(dev, dtype)
+        ge = torch.randn(data[K.EDGE_EMBEDDING].shape, generator=g, dtype=torch.float64).to(dev, dtype)
+        gv = torch.randn(data[K.EDGE_VECTORS].shape, generator=g, dtype=torch.float64).to(dev, dtype)
+        gl = torch.randn(data[K.EDGE_LENGTH].shape, generator=g, dtype=torch.float64).to(dev, dtype)
+        loss = (data[K.EDGE_ATTRS] * ga).sum() + (data[K.EDGE_EMBEDDING] * ge).sum() + (data[K.EDGE_VECTORS] * gv).sum() + (data[K.EDGE_LENGTH] * gl).sum()
+        dpos, dbw = torch.autograd.grad(loss, [data[K.POSITIONS], rb.basis.bessel_weights])
+        return data, dpos, dbw
+
+    dr, pr, br = run(R, "cpu", torch.float64)
+    dg, pg, bg = run(H, device, torch.float32)
+    for key in (K.EDGE_VECTORS, K.EDGE_LENGTH, K.EDGE_ATTRS, K.EDGE_EMBEDDING):
+        assert rel(dg[key], dr[key]) < TOL, key
+    assert rel(pg, pr) < TOL
+    assert rel(bg, br) < TOL
+
+
+def test_c_abi_rejects_bad_arguments(device):
+    """Error convention of the C ABI: negative code + message, no launch."""
+    import ctypes as C
+
+    from matten_amd import _lib
+
+    L = _lib.lib()
+    bad = (_lib.Path * 1)()
+    bad[0].l1, bad[0].l2, bad[0].l3, bad[0].mul = 5, 0, 5, 4
+    out = C.c_void_p()
+    rc = L.tfc_conv_plan_create(bad, 1, 44, 1, 44, 4, C.byref(out))
+    assert rc == -2 and b"outside" in L.tfc_last_error()
+    bad[0].l1, bad[0].l3 = 1, 3  # triangle violation with l2 = 0
+    rc = L.tfc_conv_plan_create(bad, 1, 44, 1, 44, 4, C.byref(out))
+    assert rc == -1
+    assert L.tfc_conv_fwd(None, None, None, None, None, None, None, 1, 1, 1.0, None, None, None) == -1
