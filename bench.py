@@ -1,0 +1,275 @@
+#!/usr/bin/env python
+"""bench.py - conv edges/sec, forward + backward, of the tensor-field convolution hot path.
+
+    python bench.py --gpus N --steps K --warmup W [--workload c3|c4|c5]
+    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+One step = one pass of the hot path over one synthetic batch, inputs already resident in HBM:
+edge encoders (spherical harmonics + Bessel) -> 3 x PointConvMessagePassing -> energy, then the
+backward that yields every parameter gradient AND the forces (-dE/dpos), then (N > 1) one flat
+gradient all-reduce over RCCL.  Work is data parallel over whole graphs, per-GPU batch fixed
+(weak scaling), no edge sharding.  value = sum over ranks of (edges x conv layers) / max-rank time.
+
+Also on the JSON line: `roofline` for the dominant kernel (tfc_conv_bwd_kernel; HBM-bound;
+algorithmic bytes per SURVEY.md §8d, duration from HIP events recorded by the library on the
+launch stream inside the timed region) and `cpu_baseline` (the CPU oracle = the reference's
+unfused op order, timed on this box's host cores on a bounded sample; rank 0, N = 1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+WORKLOADS = {
+    # BASELINE.md §3 / SURVEY.md §8d
+    "c3": dict(n=4, a=2.5, graphs=32, emb=64, lmax=2, irreps="64x0o+64x0e+64x1o+64x1e+64x2o+64x2e", layers=3,
+               desc="config 3: jittered simple-cubic 4^3=64 atoms, a=2.5, r_cut=5, batch 32, lmax=2, 64 channels"),
+    "c4": dict(n=6, a=2.5, graphs=32, emb=128, lmax=3,
+               irreps="128x0o+128x0e+128x1o+128x1e+128x2o+128x2e+128x3o+128x3e", layers=3,
+               desc="config 4: 6^3=216 atoms, a=2.5, r_cut=5, batch 32 per GPU, lmax=3, 128 channels"),
+    "c5": dict(n=12, a=2.1, graphs=1, emb=64, lmax=2, irreps="64x0o+64x0e+64x1o+64x1e+64x2o+64x2e", layers=3,
+               desc="config 5: 12^3=1728 atoms, a=2.1, r_cut=5, 1 structure per GPU, lmax=2, 64 channels"),
+}
+R_CUT = 5.0
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec
+
+
+def conv_layer_bytes(layer, n_nodes, n_edges):
+    """Algorithmic bytes of one forward / backward conv launch:
+    B_fwd = 4(D_in + S + W) + 16 + 4 D_mid/deg ;  B_bwd = 4(D_mid + D_in + S + W) + 16 + 4(W + S) + 4 D_in/deg."""
+    core = layer.message_fn.tp.tp
+    d_in, s, d_mid, w = core.irreps_in1.dim, core.irreps_in2.dim, core.irreps_out.dim, core.weight_numel
+    deg = n_edges / max(n_nodes, 1)
+    b_fwd = 4 * (d_in + s + w) + 16 + 4 * d_mid / deg
+    b_bwd = 4 * (d_mid + d_in + s + w) + 16 + 4 * (w + s) + 4 * d_in / deg
+    return b_fwd * n_edges, b_bwd * n_edges, dict(d_in=d_in, s=s, d_mid=d_mid, w=w)
+
+
+def build_batch(wl, rank, device):
+    from matten_amd.data.crystal import synthetic_batch
+    from matten_amd.harness import species_index
+    from matten_amd import keys as K
+
+    batch, _ = synthetic_batch(wl["n"], wl["a"], wl["graphs"], seed0=1000 + rank * wl["graphs"], r_cut=R_CUT)
+    deg = batch[K.EDGE_INDEX].shape[1] / batch[K.POSITIONS].shape[0]
+    batch["species_index"] = species_index(batch[K.ATOMIC_NUMBERS])
+    batch = {k: v.to(device) for k, v in batch.items()}
+    return batch, deg
+
+
+def cpu_baseline(wl, avg_neigh, state, n_graphs_sample, threads):
+    """The oracle (reference op order, unfused, autograd backward) on the host cores."""
+    from matten_amd import keys as K
+    from matten_amd.data.crystal import synthetic_batch
+    from matten_amd.harness import ConvStack, species_index
+    from oracle import eigenn_ref as R
+
+    torch.set_num_threads(threads)
+    batch, _ = synthetic_batch(wl["n"], wl["a"], n_graphs_sample, seed0=1000, r_cut=R_CUT)
+    batch["species_index"] = species_index(batch[K.ATOMIC_NUMBERS])
+    model = ConvStack(R, wl["emb"], wl["lmax"], wl["irreps"], wl["layers"], 64, 2, R_CUT, avg_neigh)
+    model.load_state_dict(state)
+    params = list(model.parameters())
+    n_edges = int(batch[K.EDGE_INDEX].shape[1])
+
+    def step():
+        b = dict(batch)
+        b[K.POSITIONS] = batch[K.POSITIONS].clone().requires_grad_(True)
+        _, energy, _ = model(b, n_graphs_sample)
+        torch.autograd.grad(energy.sum(), [b[K.POSITIONS]] + params, allow_unused=True)
+
+    step()  # warm-up
+    times = []
+    t_budget = time.time()
+    while len(times) < 3 or (time.time() - t_budget < 10.0 and len(times) < 10):
+        t0 = time.time()
+        step()
+        times.append(time.time() - t0)
+    med = sorted(times)[len(times) // 2]
+    return {
+        "value": n_edges * wl["layers"] / med,
+        "unit": "edges/s",
+        "cores": threads,
+        "kind": "port",
+        "sample": f"{n_graphs_sample} of the {wl['graphs']} graphs of the batch ({n_edges} edges), median of {len(times)} fwd+bwd steps, fp32",
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", default="c3", choices=sorted(WORKLOADS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--check", action="store_true", help="also verify a small case against the oracle before timing")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    device = torch.device("cuda", local_rank)
+    torch.cuda.set_device(device)
+
+    import matten_amd.nn as H
+    from matten_amd import _lib
+    from matten_amd import keys as K
+    from matten_amd.harness import ConvStack
+
+    wl = WORKLOADS[args.workload]
+    if args.check and rank == 0:
+        from tests.parity import run_layer_parity
+
+        r = run_layer_parity("smoke", device=str(device))
+        assert r["ok"], f"parity check failed: {r['worst']}"
+
+    batch, deg = build_batch(wl, rank, device)
+    n_nodes, n_edges = int(batch[K.POSITIONS].shape[0]), int(batch[K.EDGE_INDEX].shape[1])
+    avg_neigh = 28.0 if wl["a"] > 2.2 else 56.0  # dataset constant (same on every rank)
+    torch.manual_seed(35)
+    model = ConvStack(H, wl["emb"], wl["lmax"], wl["irreps"], wl["layers"], 64, 2, R_CUT, avg_neigh)
+    state = {k: v.clone() for k, v in model.state_dict().items()}
+    model = model.to(device)
+    params = list(model.parameters())
+
+    # one flat gradient bucket; param.grad are views into it => one all-reduce, no copies
+    flat = torch.zeros(sum(p.numel() for p in params), dtype=torch.float32, device=device)
+    off = 0
+    for p in params:
+        p.grad = flat[off : off + p.numel()].view_as(p)
+        off += p.numel()
+
+    pos0 = batch[K.POSITIONS]
+
+    def step():
+        flat.zero_()
+        b = dict(batch)
+        pos = pos0.detach().requires_grad_(True)
+        b[K.POSITIONS] = pos
+        _, energy, _ = model(b, wl["graphs"])
+        energy.sum().backward()
+        if dist is not None:
+            dist.all_reduce(flat)
+            flat.div_(world)
+        return pos.grad  # = -forces
+
+    def sync():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    sync()
+    L = _lib.lib()
+    L.tfc_profile_reset()
+    L.tfc_profile_enable(1)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    sync()
+    elapsed = time.perf_counter() - t0
+    L.tfc_profile_enable(0)
+    prof = _lib.profile_report()
+
+    t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+    e = torch.tensor([float(n_edges)], dtype=torch.float64, device=device)
+    if dist is not None:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dist.all_reduce(e, op=dist.ReduceOp.SUM)
+    elapsed, total_edges = float(t.item()), float(e.item())
+
+    if rank == 0:
+        ms = elapsed / args.steps * 1e3
+        value = total_edges * wl["layers"] / (elapsed / args.steps)
+        # roofline of the dominant kernel
+        fb = bb = 0.0
+        shapes = []
+        for layer in model.convs:
+            f, b, sh = conv_layer_bytes(layer, n_nodes, n_edges)
+            fb += f
+            bb += b
+            shapes.append(sh)
+        kern = {k: {"launches": c, "avg_ms": tot / c} for k, (c, tot) in prof.items()}
+        n_layers = len(model.convs)
+        roof = None
+        if "tfc_conv_bwd_kernel" in prof:
+            c, tot = prof["tfc_conv_bwd_kernel"]
+            avg_s = tot / c * 1e-3
+            bytes_per_launch = bb / n_layers
+            ach = bytes_per_launch / avg_s / 1e9
+            roof = {
+                "kernel": "tfc_conv_bwd_kernel",
+                "bound": "hbm",
+                "achieved": ach,
+                "peak": HBM_PEAK_GBS,
+                "unit": "GB/s",
+                "frac": ach / HBM_PEAK_GBS,
+                "traffic": None,
+                "bytes_per_launch": bytes_per_launch,
+                "avg_launch_ms": tot / c,
+            }
+            if "tfc_conv_fwd_kernel" in prof:
+                c2, tot2 = prof["tfc_conv_fwd_kernel"]
+                ach2 = (fb / n_layers) / (tot2 / c2 * 1e-3) / 1e9
+                roof["fwd_kernel"] = {"achieved": ach2, "frac": ach2 / HBM_PEAK_GBS, "avg_launch_ms": tot2 / c2,
+                                      "bytes_per_launch": fb / n_layers}
+        cpu = None
+        if world == 1 and not args.no_cpu_baseline:
+            threads = min(16, os.cpu_count() or 1)
+            sample = {"c3": 4, "c4": 1, "c5": 1}[args.workload]
+            try:
+                cpu = cpu_baseline(wl, avg_neigh, state, sample, threads)
+            except Exception as ex:  # the baseline is a report, never a reason to lose the GPU number
+                cpu = {"value": None, "unit": "edges/s", "cores": threads, "kind": "port", "sample": f"failed: {ex}"}
+        out = {
+            "metric": "conv edges/sec fwd+bwd",
+            "value": value,
+            "unit": "edges/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": ms,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {
+                "workload": wl["desc"],
+                "nodes_per_gpu": n_nodes,
+                "edges_per_gpu": n_edges,
+                "conv_layers": wl["layers"],
+                "step": "edge encoders + 3 conv layers forward, backward to all parameters and positions (forces)"
+                + (", flat RCCL gradient all-reduce" if world > 1 else ""),
+                "parallelism": f"dp{world}",
+                "layer_shapes": shapes,
+            },
+            "roofline": roof,
+            "cpu_baseline": cpu,
+            "kernels": kern,
+        }
+        print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -207,6 +207,9 @@ typedef struct tfc_gemm_desc {
     int32_t epilogue;   /* TFC_EPI_* */
     const float* aux;   /* TFC_EPI_SSP_GRAD: activation output h, addressed like C */
     float act_cst;      /* normalize2mom constant of the activation */
+    float* workspace;   /* optional scratch for split-K (small m x n, long k); null: never split */
+    int64_t workspace_floats;
+    const char* tag;    /* optional name under which tfc_profile_report() books this call */
 } tfc_gemm_desc;
 
 #define TFC_EPI_NONE 0
@@ -214,6 +217,9 @@ typedef struct tfc_gemm_desc {
 #define TFC_EPI_SSP_GRAD 2 /* v = v * d act/d pre, recovered from aux = act output            */
 
 int tfc_gemm(const tfc_gemm_desc* desc, tfc_stream_t stream);
+/* scratch floats with which tfc_gemm can cut K to fill the chip (0: the problem is not split).
+ * Split sums are deterministic: partial tiles are stored and added in a fixed order. */
+int64_t tfc_gemm_workspace_floats(int64_t m, int64_t n, int64_t k);
 
 /* ------------------------------------------------------------------------------------------
  * Gate non-linearity (e3nn.nn.Gate built at eigenn/nn/utils.py:134-140, applied at
@@ -241,6 +247,18 @@ int tfc_gate_fwd(const tfc_gate_seg* segs, int32_t n_segs, const float* x, int64
                  int32_t d_in, int32_t d_out, float* out, tfc_stream_t stream);
 int tfc_gate_bwd(const tfc_gate_seg* segs, int32_t n_segs, const float* x, const float* gout,
                  int64_t n_rows, int32_t d_in, int32_t d_out, float* dx, tfc_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Opt-in kernel timing (no counterpart in the reference, whose only timer is the epoch wall
+ * clock, eigenn/model/utils.py:4-35).  While enabled, every main kernel launch is bracketed by
+ * HIP events on its own stream.  tfc_profile_report() synchronises on those events and writes
+ * one "kernel_name launches total_ms" line per kernel into `buf`; it returns the number of
+ * lines (>= 0) or a negative TFC_E* code.  This is the library's only global mutable state
+ * besides the error string (mutex protected); off by default.
+ */
+int tfc_profile_enable(int on);
+int tfc_profile_reset(void);
+int tfc_profile_report(char* buf, int64_t buf_len);
 
 #ifdef __cplusplus
 }

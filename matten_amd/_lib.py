@@ -58,6 +58,9 @@ class GemmDesc(C.Structure):
         ("epilogue", C.c_int32),
         ("aux", C.c_void_p),
         ("act_cst", C.c_float),
+        ("workspace", C.c_void_p),
+        ("workspace_floats", C.c_int64),
+        ("tag", C.c_char_p),
     ]
 
 
@@ -100,7 +103,11 @@ SIGNATURES = {
     "tfc_edge_encode_bwd": (C.c_int, [_P, _P, _I64, _I32, _P, _I32, _F, _F, _P, _P, _P, _P, _P, _P, _P]),
     "tfc_edge_vec_bwd": (C.c_int, [_P, _P, _P, _P, _P, _I64, _P, _P]),
     "tfc_gemm": (C.c_int, [C.POINTER(GemmDesc), _P]),
+    "tfc_gemm_workspace_floats": (_I64, [_I64, _I64, _I64]),
     "tfc_gate_fwd": (C.c_int, [C.POINTER(GateSeg), _I32, _P, _I64, _I32, _I32, _P, _P]),
+    "tfc_profile_enable": (C.c_int, [C.c_int]),
+    "tfc_profile_reset": (C.c_int, []),
+    "tfc_profile_report": (C.c_int, [C.c_char_p, _I64]),
     "tfc_gate_bwd": (C.c_int, [C.POINTER(GateSeg), _I32, _P, _P, _I64, _I32, _I32, _P, _P]),
 }
 
@@ -137,3 +144,16 @@ def real_cg(l1: int, l2: int, l3: int):
     buf = (C.c_double * n)()
     check(lib().tfc_real_cg(l1, l2, l3, buf))
     return list(buf)
+
+
+def profile_report():
+    """{kernel name: (launches, total ms)} from the library's event timers (synchronises)."""
+    buf = C.create_string_buffer(1 << 16)
+    n = lib().tfc_profile_report(buf, len(buf))
+    if n < 0:
+        check(n)
+    out = {}
+    for line in buf.value.decode().splitlines():
+        name, cnt, ms = line.split()
+        out[name] = (int(cnt), float(ms))
+    return out

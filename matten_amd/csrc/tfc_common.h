@@ -30,6 +30,16 @@ int tfc_set_error(int code, const char* fmt, ...);
             return tfc_set_error(TFC_ELAUNCH, "launch of %s failed: %s", name, hipGetErrorString(_e)); \
     } while (0)
 
+// opt-in per-kernel timing (tfc_prof.hip): events on the launch stream around a launch
+int tfc_prof_begin(const char* name, hipStream_t stream);
+void tfc_prof_end(int idx, hipStream_t stream);
+struct TfcProfScope {
+    int idx;
+    hipStream_t stream;
+    TfcProfScope(const char* name, hipStream_t s) : idx(tfc_prof_begin(name, s)), stream(s) {}
+    ~TfcProfScope() { tfc_prof_end(idx, stream); }
+};
+
 // Blocks b and b+8 share an XCD (round-robin dispatch).  Map the hardware block id to a
 // virtual id so that each XCD walks one contiguous slab of the virtual range: neighbouring
 // virtual blocks (which gather the same rows) then share an L2.  Bijective for any n.

@@ -576,6 +576,7 @@ extern "C" int tfc_conv_fwd(const tfc_conv_plan* pl, const float* x, const float
     TFC_REQUIRE(n_edges == 0 || (y && w && eid && nbr && workspace), TFC_EINVAL, "tfc_conv_fwd: null tensor");
     float* M = workspace;
     if (n_edges > 0) {
+        TfcProfScope prof("tfc_m_prepass_kernel", stream);
         tfc_m_prepass_kernel<<<grid_for(n_edges * (long)pl->msz, 256), 256, 0, stream>>>(
             y, eid, pl->ments, pl->cgm, (long)n_edges, pl->msz, pl->d_sh, M);
         TFC_LAUNCH_CHECK("tfc_m_prepass_kernel");
@@ -583,9 +584,12 @@ extern "C" int tfc_conv_fwd(const tfc_conv_plan* pl, const float* x, const float
     const long n_tasks = (long)n_nodes * pl->n_fwd_items;
     const long n_blocks = (n_tasks + 3) / 4;
     TFC_REQUIRE(n_blocks < (1LL << 31), TFC_EUNSUPPORTED, "tfc_conv_fwd: grid too large");
-    tfc_conv_fwd_kernel<<<(unsigned)n_blocks, 256, 0, stream>>>(
-        x, w, M, row_ptr, eid, nbr, pl->paths, pl->fwd_items, pl->n_fwd_items, n_tasks, pl->d_in, pl->d_out,
-        pl->w_numel, pl->msz, scale, out);
+    {
+        TfcProfScope prof("tfc_conv_fwd_kernel", stream);
+        tfc_conv_fwd_kernel<<<(unsigned)n_blocks, 256, 0, stream>>>(
+            x, w, M, row_ptr, eid, nbr, pl->paths, pl->fwd_items, pl->n_fwd_items, n_tasks, pl->d_in, pl->d_out,
+            pl->w_numel, pl->msz, scale, out);
+    }
     TFC_LAUNCH_CHECK("tfc_conv_fwd_kernel");
     return TFC_OK;
 }
@@ -610,6 +614,7 @@ extern "C" int tfc_conv_bwd(const tfc_conv_plan* pl, const float* x, const float
         dx, (long)n_nodes * pl->d_in, 0.f);
     TFC_LAUNCH_CHECK("tfc_fill_kernel");
     if (n_edges > 0) {
+        TfcProfScope prof("tfc_m_prepass_kernel", stream);
         tfc_m_prepass_kernel<<<grid_for(n_edges * (long)pl->msz, 256), 256, 0, stream>>>(
             y, eid, pl->ments, pl->cgm, (long)n_edges, pl->msz, pl->d_sh, M);
         TFC_LAUNCH_CHECK("tfc_m_prepass_kernel");
@@ -618,16 +623,21 @@ extern "C" int tfc_conv_bwd(const tfc_conv_plan* pl, const float* x, const float
     const long n_blocks = (n_tasks + 3) / 4;
     TFC_REQUIRE(n_blocks < (1LL << 31), TFC_EUNSUPPORTED, "tfc_conv_bwd: grid too large");
     if (dy) {
-        tfc_conv_bwd_kernel<true><<<(unsigned)n_blocks, 256, 0, stream>>>(
-            x, w, gout, M, pl->cgd, row_ptr, eid, nbr, pl->paths, pl->bwd_items, pl->grp_paths,
-            pl->n_bwd_items, n_tasks, pl->d_in, pl->d_out, pl->w_numel, pl->msz, pl->py, scale, dx, dw, dyp);
+        {
+            TfcProfScope prof("tfc_conv_bwd_kernel", stream);
+            tfc_conv_bwd_kernel<true><<<(unsigned)n_blocks, 256, 0, stream>>>(
+                x, w, gout, M, pl->cgd, row_ptr, eid, nbr, pl->paths, pl->bwd_items, pl->grp_paths,
+                pl->n_bwd_items, n_tasks, pl->d_in, pl->d_out, pl->w_numel, pl->msz, pl->py, scale, dx, dw, dyp);
+        }
         TFC_LAUNCH_CHECK("tfc_conv_bwd_kernel<dy>");
         if (n_edges > 0) {
+            TfcProfScope prof("tfc_dy_reduce_kernel", stream);
             tfc_dy_reduce_kernel<<<grid_for(n_edges * (long)pl->d_sh, 256, 2048), 256, 0, stream>>>(
                 dyp, pl->ylist_ptr, pl->ylist, (long)n_edges, pl->d_sh, pl->py, dy);
             TFC_LAUNCH_CHECK("tfc_dy_reduce_kernel");
         }
     } else {
+        TfcProfScope prof("tfc_conv_bwd_kernel", stream);
         tfc_conv_bwd_kernel<false><<<(unsigned)n_blocks, 256, 0, stream>>>(
             x, w, gout, M, pl->cgd, row_ptr, eid, nbr, pl->paths, pl->bwd_items, pl->grp_paths,
             pl->n_bwd_items, n_tasks, pl->d_in, pl->d_out, pl->w_numel, pl->msz, pl->py, scale, dx, dw,

@@ -278,6 +278,7 @@ extern "C" int tfc_edge_encode_fwd(const float* pos, const int64_t* edge_index, 
     TFC_REQUIRE(!shift || (cell && n_graphs >= 1), TFC_EINVAL, "tfc_edge_encode_fwd: shift without cell");
     TFC_REQUIRE(!shift || n_graphs == 1 || batch, TFC_EINVAL, "tfc_edge_encode_fwd: batched cell without batch");
     const int grid = (int)std::min<long>((n_edges + 255) / 256, 8192);
+    TfcProfScope prof("tfc_edge_fwd_kernel", stream);
     tfc_edge_fwd_kernel<<<grid, 256, 0, stream>>>(pos, edge_index, shift, cell, batch, (long)n_edges,
                                                   (long)n_nodes, (long)n_graphs, sh ? lmax : 0, bw, n_basis,
                                                   r_max, p, vec, pos ? len : nullptr, pos ? nullptr : len, sh,
@@ -308,6 +309,7 @@ extern "C" int tfc_edge_encode_bwd(const float* vec, const float* len, int64_t n
         return TFC_OK;
     }
     TFC_REQUIRE(vec && dvec, TFC_EINVAL, "tfc_edge_encode_bwd: null tensor");
+    TfcProfScope prof("tfc_edge_bwd_kernel", stream);
     tfc_edge_bwd_kernel<<<grid, EDGE_BWD_BLOCK, 0, stream>>>(vec, len, (long)n_edges, dsh ? lmax : 0, bw, n_basis,
                                                              r_max, p, dsh, demb, dvec_add, dlen, dvec,
                                                              dbw_partial);

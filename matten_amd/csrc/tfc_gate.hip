@@ -137,6 +137,7 @@ extern "C" int tfc_gate_fwd(const tfc_gate_seg* segs, int32_t n_segs, const floa
     if (n_rows == 0) return TFC_OK;
     TFC_REQUIRE(x && out, TFC_EINVAL, "tfc_gate_fwd: null tensor");
     const int grid = (int)std::min<long>((n_rows * (long)d_out + 255) / 256, 8192);
+    TfcProfScope prof("tfc_gate_fwd_kernel", stream);
     tfc_gate_fwd_kernel<<<grid, 256, 0, stream>>>(g, x, (long)n_rows, d_in, d_out, out);
     TFC_LAUNCH_CHECK("tfc_gate_fwd_kernel");
     return TFC_OK;
@@ -152,6 +153,7 @@ extern "C" int tfc_gate_bwd(const tfc_gate_seg* segs, int32_t n_segs, const floa
     if (n_rows == 0) return TFC_OK;
     TFC_REQUIRE(x && gout && dx, TFC_EINVAL, "tfc_gate_bwd: null tensor");
     const int grid = (int)std::min<long>((n_rows * (long)d_in + 255) / 256, 8192);
+    TfcProfScope prof("tfc_gate_bwd_kernel", stream);
     tfc_gate_bwd_kernel<<<grid, 256, 0, stream>>>(g, x, gout, (long)n_rows, d_in, d_out, dx);
     TFC_LAUNCH_CHECK("tfc_gate_bwd_kernel");
     return TFC_OK;

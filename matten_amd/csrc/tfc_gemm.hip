@@ -42,6 +42,8 @@ struct GemmArgs {
     IMapD a1_r, a1_k, a2_r, a2_k, b_k, b_j, c_r, c_j;
     float alpha, act_cst;
     int accumulate, epilogue;
+    int splits;      // > 1: K is cut into `splits` ranges, raw partial tiles go to `slab`
+    float* slab;     // [splits][m][n]
 };
 
 __device__ __forceinline__ long imap_eval(const IMapD& m, long t) {
@@ -87,11 +89,11 @@ struct Operand {
     float v[NE];
 
     __device__ __forceinline__ void init(const IMapD& mx, const IMapD& mk, const IMapD& mx2, const IMapD& mk2,
-                                         long x0, long xmax, int t) {
+                                         long x0, long xmax, int t, long kstart) {
         if (KFAST) {
             kk[0] = t % BK;
-            kt[0].init(mk, kk[0]);
-            if (HAS2) kt2[0].init(mk2, kk[0]);
+            kt[0].init(mk, kstart + kk[0]);
+            if (HAS2) kt2[0].init(mk2, kstart + kk[0]);
 #pragma unroll
             for (int q = 0; q < NE; ++q) {
                 long x = x0 + t / BK + (256 / BK) * q;
@@ -107,8 +109,8 @@ struct Operand {
 #pragma unroll
             for (int q = 0; q < NE; ++q) {
                 kk[q] = t / BX + (256 / BX) * q;
-                kt[q].init(mk, kk[q]);
-                if (HAS2) kt2[q].init(mk2, kk[q]);
+                kt[q].init(mk, kstart + kk[q]);
+                if (HAS2) kt2[q].init(mk2, kstart + kk[q]);
             }
         }
     }
@@ -173,15 +175,21 @@ __global__ __launch_bounds__(256) void tfc_gemm_kernel(const GemmArgs g) {
 
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int wm = wave >> 1, wn = wave & 1;
-    const long nbm = (g.m + BM - 1) / BM;
+    const long nbm = (g.m + BM - 1) / BM, nbn = (g.n + BN - 1) / BN;
     const unsigned vb = tfc_xcd_remap(blockIdx.x, gridDim.x);
-    const long bm = vb % nbm, bn = vb / nbm;  // consecutive blocks share the B tile
+    const long tile = vb % (nbm * nbn);
+    const int z = (int)(vb / (nbm * nbn));      // K range of this block
+    const long bm = tile % nbm, bn = tile / nbm;  // consecutive blocks share the B tile
     const long r0 = bm * BM, j0 = bn * BN;
+    const long nkt_all = (g.k + BK - 1) / BK;
+    const long per = (nkt_all + g.splits - 1) / g.splits;
+    const long kt_begin = z * per;
+    const long kt_end = kt_begin + per < nkt_all ? kt_begin + per : nkt_all;
 
     Operand<BM, A_KFAST, HAS2> A;
     Operand<BN, B_KFAST, false> B;
-    A.init(g.a1_r, g.a1_k, g.a2_r, g.a2_k, r0, g.m, t);
-    B.init(g.b_j, g.b_k, g.b_j, g.b_k, j0, g.n, t);
+    A.init(g.a1_r, g.a1_k, g.a2_r, g.a2_k, r0, g.m, t, kt_begin * BK);
+    B.init(g.b_j, g.b_k, g.b_j, g.b_k, j0, g.n, t, kt_begin * BK);
 
     floatx16 acc[TM][TN];
 #pragma unroll
@@ -191,10 +199,10 @@ __global__ __launch_bounds__(256) void tfc_gemm_kernel(const GemmArgs g) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    const long nkt = (g.k + BK - 1) / BK;
-    A.load(g.a1, g.a2, 0, g.k);
-    B.load(g.b, nullptr, 0, g.k);
-    for (long kt = 0; kt < nkt; ++kt) {
+    const long nkt = kt_end;
+    A.load(g.a1, g.a2, kt_begin * BK, g.k);
+    B.load(g.b, nullptr, kt_begin * BK, g.k);
+    for (long kt = kt_begin; kt < nkt; ++kt) {
         A.store(As, t);
         B.store(Bs, t);
         __syncthreads();
@@ -234,6 +242,10 @@ __global__ __launch_bounds__(256) void tfc_gemm_kernel(const GemmArgs g) {
             for (int reg = 0; reg < 16; ++reg) {
                 const long row = r0 + wm * 32 * TM + i * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * half;
                 if (row >= g.m) continue;
+                if (g.splits > 1) {
+                    g.slab[((long)z * g.m + row) * g.n + col] = acc[i][j][reg];
+                    continue;
+                }
                 const long o = imap_eval(g.c_r, row) + co;
                 float v = g.alpha * acc[i][j][reg];
                 if (g.epilogue == TFC_EPI_SSP) v = ssp_act(v, g.act_cst);
@@ -242,6 +254,23 @@ __global__ __launch_bounds__(256) void tfc_gemm_kernel(const GemmArgs g) {
                 g.c[o] = v;
             }
         }
+    }
+}
+
+// second stage of split-K: ordered sum of the partial slabs, then the usual epilogue
+__global__ __launch_bounds__(256) void tfc_gemm_reduce_kernel(const GemmArgs g) {
+    const long total = g.m * g.n;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (long)gridDim.x * blockDim.x) {
+        const long row = i / g.n, col = i - row * g.n;
+        float s = 0.f;
+        for (int z = 0; z < g.splits; ++z) s += g.slab[(long)z * total + i];
+        const long o = imap_eval(g.c_r, row) + imap_eval(g.c_j, col);
+        float v = g.alpha * s;
+        if (g.epilogue == TFC_EPI_SSP) v = ssp_act(v, g.act_cst);
+        if (g.epilogue == TFC_EPI_SSP_GRAD) v *= ssp_grad_from_out(g.aux[o], g.act_cst);
+        if (g.accumulate) v += g.c[o];
+        g.c[o] = v;
     }
 }
 
@@ -269,11 +298,12 @@ long map_unit_step(const tfc_imap& m) {  // f(1) - f(0)
 }
 
 template <int TM, int TN>
-int launch_tile(const GemmArgs& g, bool a_kfast, bool b_kfast, bool has2, hipStream_t stream) {
+int launch_tile(const GemmArgs& g, bool a_kfast, bool b_kfast, bool has2, const char* tag, hipStream_t stream) {
     constexpr int BM = 64 * TM, BN = 64 * TN;
-    const long nb = ((g.m + BM - 1) / BM) * ((g.n + BN - 1) / BN);
+    const long nb = ((g.m + BM - 1) / BM) * ((g.n + BN - 1) / BN) * g.splits;
     TFC_REQUIRE(nb < (1LL << 31), TFC_EUNSUPPORTED, "tfc_gemm: grid too large");
     const dim3 grid((unsigned)nb), block(256);
+    TfcProfScope prof(tag, stream);
 #define TFC_GEMM_LAUNCH(AK, BKF, H2) tfc_gemm_kernel<TM, TN, AK, BKF, H2><<<grid, block, 0, stream>>>(g)
     if (has2) {
         if (a_kfast) {
@@ -290,6 +320,11 @@ int launch_tile(const GemmArgs& g, bool a_kfast, bool b_kfast, bool has2, hipStr
     }
 #undef TFC_GEMM_LAUNCH
     TFC_LAUNCH_CHECK("tfc_gemm_kernel");
+    if (g.splits > 1) {
+        const long total = g.m * g.n;
+        tfc_gemm_reduce_kernel<<<(unsigned)std::min<long>((total + 255) / 256, 4096), 256, 0, stream>>>(g);
+        TFC_LAUNCH_CHECK("tfc_gemm_reduce_kernel");
+    }
     return TFC_OK;
 }
 
@@ -340,10 +375,36 @@ extern "C" int tfc_gemm(const tfc_gemm_desc* d, tfc_stream_t stream_) {
     const bool b_kfast = (map_unit_step(d->b_k) == 1 && map_unit_step(d->b_j) != 1);
     const bool has2 = d->a2 != nullptr;
 
+    const char* tag = d->tag ? d->tag : "tfc_gemm_kernel";
+    g.splits = 1;
+    g.slab = nullptr;
     // tile: large where the problem fills the chip, small otherwise
     const long b22 = ((d->m + 127) / 128) * ((d->n + 127) / 128);
-    if (d->n > 64 && d->m > 64 && b22 >= 256) return launch_tile<2, 2>(g, a_kfast, b_kfast, has2, stream);
+    if (d->n > 64 && d->m > 64 && b22 >= 256) return launch_tile<2, 2>(g, a_kfast, b_kfast, has2, tag, stream);
     if (d->n <= 64 && d->m > 64 && ((d->m + 127) / 128) >= 256)
-        return launch_tile<2, 1>(g, a_kfast, b_kfast, has2, stream);
-    return launch_tile<1, 1>(g, a_kfast, b_kfast, has2, stream);
+        return launch_tile<2, 1>(g, a_kfast, b_kfast, has2, tag, stream);
+    // small grids with a long K: cut K so that the chip is filled (deterministic: partial tiles
+    // go to the caller's workspace and are summed in a fixed order)
+    const long b11 = ((d->m + 63) / 64) * ((d->n + 63) / 64);
+    const long nkt = (d->k + BK - 1) / BK;
+    if (b11 < 256 && nkt >= 16 && d->workspace) {
+        long splits = std::min<long>((512 + b11 - 1) / b11, nkt / 8);
+        splits = std::min<long>(splits, d->workspace_floats / std::max<long>(d->m * d->n, 1));
+        if (splits > 1) {
+            const long per = (nkt + splits - 1) / splits;
+            splits = (nkt + per - 1) / per;  // no empty range
+            g.splits = (int)splits;
+            g.slab = d->workspace;
+        }
+    }
+    return launch_tile<1, 1>(g, a_kfast, b_kfast, has2, tag, stream);
+}
+
+extern "C" int64_t tfc_gemm_workspace_floats(int64_t m, int64_t n, int64_t k) {
+    if (m <= 0 || n <= 0 || k <= 0) return 0;
+    const long b11 = ((m + 63) / 64) * ((n + 63) / 64);
+    const long nkt = (k + BK - 1) / BK;
+    if (b11 >= 256 || nkt < 16) return 0;
+    const long splits = std::min<long>((512 + b11 - 1) / b11, nkt / 8);
+    return splits > 1 ? splits * m * n : 0;
 }

@@ -444,9 +444,27 @@ def _lin(stride) -> IMap:  # f(t) = t * stride
     return _imap(1, 1, stride, 0, 0)
 
 
+_GEMM_WS: "dict[int, torch.Tensor]" = {}
+
+
+def _gemm_workspace(n_floats: int) -> torch.Tensor:
+    """Per-device scratch for split-K, reused by every call (calls are stream ordered)."""
+    dev = torch.cuda.current_device()
+    ws = _GEMM_WS.get(dev)
+    if ws is None or ws.numel() < n_floats:
+        ws = torch.empty(max(n_floats, 1 << 22), dtype=torch.float32, device=torch.device("cuda", dev))
+        _GEMM_WS[dev] = ws
+    return ws
+
+
 def _gemm(m, n, k, a1, b, c, a1_r, a1_k, b_k, b_j, c_r, c_j, alpha=1.0, accumulate=False, a2=None, a2_r=None, a2_k=None,
-          epilogue=_lib.EPI_NONE, aux=None, act_cst=1.0):
+          epilogue=_lib.EPI_NONE, aux=None, act_cst=1.0, tag=None):
     d = GemmDesc()
+    need = int(_lib.lib().tfc_gemm_workspace_floats(int(m), int(n), int(k)))
+    if need > 0:
+        ws = _gemm_workspace(need)
+        d.workspace, d.workspace_floats = ws.data_ptr(), ws.numel()
+    d.tag = tag
     d.m, d.n, d.k = int(m), int(n), int(k)
     d.a1, d.b, d.c = a1, b, c
     d.a2 = a2
@@ -496,6 +514,7 @@ class _LinearFn(torch.autograd.Function):
                 n * d, mo, mi, _p(x, in_off), _p(weight, w_off), _p(out, out_off),
                 a1_r=_imap(1, d, spec.d_in, 0, 1), a1_k=_lin(d), b_k=_lin(mo), b_j=_lin(1),
                 c_r=_imap(1, d, spec.d_out, 0, 1), c_j=_lin(d), alpha=pw, accumulate=out_off in seen,
+                tag=b"gemm_linear_fwd",
             )
             seen.add(out_off)
         ctx.save_for_backward(x, weight)
@@ -518,6 +537,7 @@ class _LinearFn(torch.autograd.Function):
                     n * d, mi, mo, _p(g, out_off), _p(weight, w_off), _p(dx, in_off),
                     a1_r=_imap(1, d, spec.d_out, 0, 1), a1_k=_lin(d), b_k=_lin(1), b_j=_lin(mo),
                     c_r=_imap(1, d, spec.d_in, 0, 1), c_j=_lin(d), alpha=pw, accumulate=in_off in seen,
+                    tag=b"gemm_linear_dx",
                 )
                 seen.add(in_off)
         if ctx.needs_input_grad[1]:
@@ -526,7 +546,7 @@ class _LinearFn(torch.autograd.Function):
                 _gemm(
                     mi, mo, n * d, _p(x, in_off), _p(g, out_off), _p(dw, w_off),
                     a1_r=_lin(d), a1_k=_imap(1, d, spec.d_in, 0, 1), b_k=_imap(1, d, spec.d_out, 0, 1), b_j=_lin(d),
-                    c_r=_lin(mo), c_j=_lin(1), alpha=pw,
+                    c_r=_lin(mo), c_j=_lin(1), alpha=pw, tag=b"gemm_linear_dw",
                 )
         return dx, dw, None
 
@@ -556,7 +576,7 @@ class _RadialMlpFn(torch.autograd.Function):
             _gemm(
                 E, hout, hin, _p(hs[-1]), _p(w), _p(out), a1_r=_lin(hin), a1_k=_lin(1), b_k=_lin(hout), b_j=_lin(1),
                 c_r=_lin(hout), c_j=_lin(1), alpha=1.0 / math.sqrt(hin),
-                epilogue=_lib.EPI_NONE if last else _lib.EPI_SSP, act_cst=act_cst,
+                epilogue=_lib.EPI_NONE if last else _lib.EPI_SSP, act_cst=act_cst, tag=b"gemm_mlp_fwd",
             )
             hs.append(out)
         ctx.save_for_backward(*hs[:-1], *ws)
@@ -578,7 +598,7 @@ class _RadialMlpFn(torch.autograd.Function):
                 dw = torch.empty_like(w)
                 _gemm(
                     hin, hout, E, _p(h), _p(g), _p(dw), a1_r=_lin(1), a1_k=_lin(hin), b_k=_lin(hout), b_j=_lin(1),
-                    c_r=_lin(hout), c_j=_lin(1), alpha=alpha,
+                    c_r=_lin(hout), c_j=_lin(1), alpha=alpha, tag=b"gemm_mlp_dw",
                 )
                 dws[i] = dw
             if i > 0 or ctx.needs_input_grad[0]:
@@ -587,7 +607,7 @@ class _RadialMlpFn(torch.autograd.Function):
                     E, hin, hout, _p(g), _p(w), _p(dh), a1_r=_lin(hout), a1_k=_lin(1), b_k=_lin(1), b_j=_lin(hout),
                     c_r=_lin(hin), c_j=_lin(1), alpha=alpha,
                     epilogue=_lib.EPI_SSP_GRAD if i > 0 else _lib.EPI_NONE, aux=_p(h) if i > 0 else None,
-                    act_cst=ctx.act_cst,
+                    act_cst=ctx.act_cst, tag=b"gemm_mlp_dh",
                 )
                 g = dh
             else:
@@ -640,7 +660,7 @@ class _FctpFn(torch.autograd.Function):
                 a1_r=_imap(1, d, spec.d_x, 0, 1), a1_k=_imap(1, mv, d, 0, 0),
                 a2=_p(a, ao), a2_r=_imap(1, d, spec.d_a, 0, 0), a2_k=_imap(1, mv, 0, 0, 1),
                 b_k=_lin(mw), b_j=_lin(1), c_r=_imap(1, d, spec.d_out, 0, 1), c_j=_lin(d), alpha=alpha,
-                accumulate=True if seen is None else (oo in seen),
+                accumulate=True if seen is None else (oo in seen), tag=b"gemm_fctp_fwd",
             )
             if seen is not None:
                 seen.add(oo)
@@ -666,7 +686,7 @@ class _FctpFn(torch.autograd.Function):
                     a1_r=_imap(1, d, spec.d_a, 0, 0), a1_k=_imap(1, mw, 1, 0, 0),
                     a2=_p(g, oo), a2_r=_imap(1, d, spec.d_out, 0, 1), a2_k=_imap(1, mw, 0, 0, d),
                     b_k=_lin(1), b_j=_lin(mv * mw), c_r=_imap(1, d, spec.d_x, 0, 1), c_j=_lin(d), alpha=alpha,
-                    accumulate=xo in seen,
+                    accumulate=xo in seen, tag=b"gemm_fctp_dx",
                 )
                 seen.add(xo)
         if ctx.needs_input_grad[1]:
@@ -679,7 +699,7 @@ class _FctpFn(torch.autograd.Function):
                     a1_r=_lin(spec.d_x), a1_k=_imap(mw, d, d, 0, 1),
                     a2=_p(g, oo), a2_r=_lin(spec.d_out), a2_k=_imap(mw, d, 0, d, 1),
                     b_k=_imap(mw, d, mv * mw, 1, 0), b_j=_lin(mw), c_r=_lin(spec.d_a), c_j=_lin(1), alpha=alpha,
-                    accumulate=ao in seen,
+                    accumulate=ao in seen, tag=b"gemm_fctp_da",
                 )
                 seen.add(ao)
         if ctx.needs_input_grad[2]:
@@ -691,6 +711,7 @@ class _FctpFn(torch.autograd.Function):
                     a1_r=_imap(1, mv, d, 0, 0), a1_k=_imap(1, d, spec.d_x, 0, 1),
                     a2=_p(a, ao), a2_r=_imap(1, mv, 0, 0, 1), a2_k=_imap(1, d, spec.d_a, 0, 0),
                     b_k=_imap(1, d, spec.d_out, 0, 1), b_j=_lin(d), c_r=_lin(mw), c_j=_lin(1), alpha=alpha,
+                    tag=b"gemm_fctp_dw",
                 )
         return dx, da, dw, None, (g if ctx.has_base else None)
 

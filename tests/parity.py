@@ -44,64 +44,15 @@ def make_batch(cfg, seed0=1000):
     return batch
 
 
-def species_index(z):
-    table = {1: 0, 6: 1, 8: 2, 14: 3}
-    return torch.tensor([table[int(v)] for v in z.tolist()], dtype=torch.long)
-
-
-class Stack(torch.nn.Module):
+def Stack(impl, cfg):
     """embedding -> SH -> radial -> conv layers, built from either implementation."""
+    from matten_amd.harness import ConvStack
 
-    def __init__(self, impl, cfg):
-        super().__init__()
-        if impl == "oracle":
-            from oracle import eigenn_ref as M
-
-            Irreps = M.Irreps
-        else:
-            import matten_amd.nn as M
-            from matten_amd.irreps import Irreps
-        self.K = __import__("matten_amd.keys", fromlist=["x"])
-        K = self.K
-        emb = cfg["emb"]
-        self.embedding = torch.nn.Embedding(4, emb)
-        irreps = {K.NODE_FEATURES: f"{emb}x0e", K.NODE_ATTRS: f"{emb}x0e", K.EDGE_INDEX: None, K.POSITIONS: "1o"}
-        self.spharm_edges = M.SphericalHarmonicEdgeAttrs(irreps_edge_sh=cfg["lmax"], irreps_in=irreps)
-        self.radial_basis = M.RadialBasisEdgeEncoding(
-            basis_kwargs={"num_basis": 8, "r_max": R_CUT}, cutoff_kwargs={"r_max": R_CUT}, irreps_in=self.spharm_edges.irreps_out
-        )
-        cur = self.radial_basis.irreps_out
-        self.convs = torch.nn.ModuleList()
-        for _ in range(cfg["layers"]):
-            layer = M.PointConvMessagePassing(
-                irreps_in=cur,
-                conv_layer_irreps=cfg["irreps"],
-                message_kwargs={"fc_num_hidden_layers": cfg["nh"], "fc_hidden_size": cfg["hidden"]},
-                update_kwargs={"use_self_connection": True, "avg_num_neighbors": AVG_NEIGH},
-                activation_type="gate",
-                use_resnet=True,
-            )
-            self.convs.append(layer)
-            cur = layer.irreps_out
-        self.d_out = Irreps(cur[K.NODE_FEATURES]).dim
-        g = torch.Generator().manual_seed(7)
-        self.register_buffer("readout", torch.randn(self.d_out, generator=g) / self.d_out**0.5)
-
-    def forward(self, batch):
-        K = self.K
-        data = dict(batch)
-        x = self.embedding(data["species_index"])
-        data[K.NODE_FEATURES] = x
-        data[K.NODE_ATTRS] = x
-        data = self.spharm_edges(data)
-        data = self.radial_basis(data)
-        for layer in self.convs:
-            data = layer(data)
-        feats = data[K.NODE_FEATURES]
-        per_atom = feats @ self.readout.to(feats.dtype)
-        n_graphs = int(data[K.BATCH].max().item()) + 1
-        energy = torch.zeros(n_graphs, dtype=feats.dtype, device=feats.device).index_add_(0, data[K.BATCH], per_atom)
-        return feats, energy, data
+    if impl == "oracle":
+        from oracle import eigenn_ref as M
+    else:
+        import matten_amd.nn as M
+    return ConvStack(M, cfg["emb"], cfg["lmax"], cfg["irreps"], cfg["layers"], cfg["hidden"], cfg["nh"], R_CUT, AVG_NEIGH)
 
 
 def _prep(batch, device, dtype):
@@ -111,6 +62,8 @@ def _prep(batch, device, dtype):
         if v.is_floating_point():
             v = v.to(dtype)
         out[k] = v.to(device)
+    from matten_amd.harness import species_index
+
     out["species_index"] = species_index(batch[K.ATOMIC_NUMBERS]).to(device)
     out[K.POSITIONS] = out[K.POSITIONS].clone().requires_grad_(True)
     return out
@@ -120,7 +73,7 @@ def run_stack(model, batch, device, dtype):
     K = __import__("matten_amd.keys", fromlist=["x"])
     model = model.to(device=device, dtype=dtype)
     b = _prep(batch, device, dtype)
-    feats, energy, data = model(b)
+    feats, energy, data = model(b, int(batch[K.BATCH].max().item()) + 1)
     params = [p for p in model.parameters()]
     grads = torch.autograd.grad(energy.sum(), [b[K.POSITIONS]] + params, allow_unused=True)
     res = {"feats": feats.detach(), "energy": energy.detach(), "forces": -grads[0].detach()}
