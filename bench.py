@@ -150,24 +150,20 @@ def main():
     params = list(model.parameters())
 
     # one flat gradient bucket; param.grad are views into it => one all-reduce, no copies
-    flat = torch.zeros(sum(p.numel() for p in params), dtype=torch.float32, device=device)
-    off = 0
-    for p in params:
-        p.grad = flat[off : off + p.numel()].view_as(p)
-        off += p.numel()
+    from matten_amd.dp import FlatGradBucket
+
+    bucket = FlatGradBucket(params)
 
     pos0 = batch[K.POSITIONS]
 
     def step():
-        flat.zero_()
+        bucket.zero()
         b = dict(batch)
         pos = pos0.detach().requires_grad_(True)
         b[K.POSITIONS] = pos
         _, energy, _ = model(b, wl["graphs"])
         energy.sum().backward()
-        if dist is not None:
-            dist.all_reduce(flat)
-            flat.div_(world)
+        bucket.all_reduce_mean()
         return pos.grad  # = -forces
 
     def sync():

@@ -92,6 +92,8 @@ class Irreps(tuple):
                         items.append(MulIrrep(int(mul), Irrep.of(ir)))
                     else:
                         items.append(MulIrrep(1, Irrep.of(term)))
+        if any(m.mul < 0 for m in items):
+            raise ValueError(f"negative multiplicity in {spec!r}")
         return super().__new__(cls, items)
 
     @staticmethod
