@@ -217,6 +217,13 @@ typedef struct tfc_gemm_desc {
 #define TFC_EPI_SSP_GRAD 2 /* v = v * d act/d pre, recovered from aux = act output            */
 
 int tfc_gemm(const tfc_gemm_desc* desc, tfc_stream_t stream);
+/* Several independent problems in as few launches as possible (problems that walk their operands
+ * the same way share a launch, so the many small per-irrep products of one o3.Linear or one
+ * FullyConnectedTensorProduct fill the chip together).  Equivalent to calling tfc_gemm on each
+ * descriptor, PROVIDED no two problems of one call write the same element of C (not checked):
+ * the order in which the problems of a call run is unspecified.  The workspace of the group is
+ * the largest one found in the descriptors. */
+int tfc_gemm_group(const tfc_gemm_desc* descs, int32_t n_descs, tfc_stream_t stream);
 /* scratch floats with which tfc_gemm can cut K to fill the chip (0: the problem is not split).
  * Split sums are deterministic: partial tiles are stored and added in a fixed order. */
 int64_t tfc_gemm_workspace_floats(int64_t m, int64_t n, int64_t k);

@@ -1,5 +1,6 @@
 // Strided fp32 GEMM on the gfx950 matrix cores (v_mfma_f32_32x32x2_f32: bit-exact fp32 fmaf
-// chains, no reduced-precision path), with decomposed index maps on every operand.
+// chains, no reduced-precision path), with decomposed index maps on every operand, launched
+// one problem at a time (tfc_gemm) or as a group of independent problems (tfc_gemm_group).
 //
 // Serves the dense pieces of the layer, forward and backward, without materialising transposes
 // or outer products:
@@ -11,149 +12,59 @@
 //   with  f(t) = (t / (d1*d2))*s0 + ((t / d2) % d1)*s1 + (t % d2)*s2  for every map.
 //
 // Block = 256 threads = 4 waves (2 x 2); block tile (64*TM) x (64*TN), K tile 16; each wave owns
-// TM x TN accumulators of 32 x 32.  Operand tiles are staged through LDS as [k][x + 2 pad]
-// (k-major so that the MFMA operand read is lane-contiguous and conflict free).  The next K tile's
-// global loads are issued before the MFMAs of the current one.
+// TM x TN accumulators of 32 x 32.  Operand tiles are staged through LDS as [k][x + 4 pad]
+// (k-major: the MFMA operand read is lane-contiguous and conflict free), double buffered, one
+// barrier per K tile, the next tile's global loads in flight during the MFMAs of the current one.
+//
+// Every operand address is rowoff(x) + koff(k).  Both are evaluated ONCE per block (rows) or
+// once per K tile by 16 threads (k) into small LDS tables, so that no thread carries per-element
+// index state in registers: the accumulators and the staging registers are all a wave holds
+// (the first version of this kernel tracked a mixed-radix index per element in VGPRs and
+// spilled at the 128 x 128 tile).
 #include "tfc_common.h"
 
 #include <algorithm>
+#include <vector>
 
 namespace {
 
 typedef float floatx16 __attribute__((ext_vector_type(16)));
 
 constexpr int BK = 16;
+constexpr int KT = 8;  // K tiles whose k offsets are evaluated together
+constexpr int MAXP = 8;  // problems per launch (the group is passed by value as kernel argument)
 
-struct IMapD {
+struct Map {
     int d1, d2;
     long s0, s1, s2;
-    // constants for advancing the index by BK (mixed-radix add)
-    int b2, B1;
-    long K0, K1, K2;
 };
 
-struct GemmArgs {
-    long m, n, k;
+struct Problem {
     const float* a1;
     const float* a2;
     const float* b;
     float* c;
     const float* aux;
-    IMapD a1_r, a1_k, a2_r, a2_k, b_k, b_j, c_r, c_j;
-    float alpha, act_cst;
+    float* slab;  // [splits][m][n] raw partial tiles when splits > 1
+    Map a1_r, a1_k, a2_r, a2_k, b_k, b_j, c_r, c_j;
+    int m, n, k;
+    int splits;       // > 1: K is cut into `splits` ranges
+    int block_begin;  // first virtual block of this problem in the launch
     int accumulate, epilogue;
-    int splits;      // > 1: K is cut into `splits` ranges, raw partial tiles go to `slab`
-    float* slab;     // [splits][m][n]
+    int a1_bc, a2_bc;  // 16-byte staging only: the factor is constant over a group of 4
+    float alpha, act_cst;
 };
 
-__device__ __forceinline__ long imap_eval(const IMapD& m, long t) {
-    if (m.d1 == 1 && m.d2 == 1) return t * m.s0;
-    const long q2 = t / m.d2, r2 = t - q2 * m.d2;
-    const long q1 = q2 / m.d1, r1 = q2 - q1 * m.d1;
-    return q1 * m.s0 + r1 * m.s1 + r2 * m.s2;
+struct Group {
+    int n;
+    Problem p[MAXP];
+};
+
+__device__ __forceinline__ long map_eval(const Map& m, int t) {
+    const int q2 = t / m.d2, r2 = t - q2 * m.d2;
+    const int q1 = q2 / m.d1, r1 = q2 - q1 * m.d1;
+    return (long)q1 * m.s0 + (long)r1 * m.s1 + (long)r2 * m.s2;
 }
-
-struct KTrack {
-    int r1, r2;
-    long off;
-    __device__ __forceinline__ void init(const IMapD& m, long t) {
-        const long q2 = t / m.d2;
-        r2 = (int)(t - q2 * m.d2);
-        const long q1 = q2 / m.d1;
-        r1 = (int)(q2 - q1 * m.d1);
-        off = q1 * m.s0 + r1 * m.s1 + r2 * m.s2;
-    }
-    __device__ __forceinline__ void step(const IMapD& m) {
-        r2 += m.b2;
-        const bool c2 = r2 >= m.d2;
-        r2 -= c2 ? m.d2 : 0;
-        r1 += m.B1 + (c2 ? 1 : 0);
-        const bool c1 = r1 >= m.d1;
-        r1 -= c1 ? m.d1 : 0;
-        off += m.K0 + (c2 ? m.K2 : 0) + (c1 ? m.K1 : 0);
-    }
-};
-
-// One operand tile [BK][BX] loaded by 256 threads.  KFAST: consecutive threads walk k (operand
-// contiguous along k); otherwise they walk x (contiguous along the row / column index).
-template <int BX, bool KFAST, bool HAS2>
-struct Operand {
-    static constexpr int NE = BX * BK / 256;     // elements per thread
-    static constexpr int NT = KFAST ? 1 : NE;    // k tracks per thread
-    static constexpr int NX = KFAST ? NE : 1;    // x offsets per thread
-    static constexpr int LDS_STRIDE = BX + 2;
-
-    KTrack kt[NT], kt2[HAS2 ? NT : 1];
-    long xo[NX], xo2[HAS2 ? NX : 1];
-    int kk[NT];  // k index inside the tile of each track
-    float v[NE];
-
-    __device__ __forceinline__ void init(const IMapD& mx, const IMapD& mk, const IMapD& mx2, const IMapD& mk2,
-                                         long x0, long xmax, int t, long kstart) {
-        if (KFAST) {
-            kk[0] = t % BK;
-            kt[0].init(mk, kstart + kk[0]);
-            if (HAS2) kt2[0].init(mk2, kstart + kk[0]);
-#pragma unroll
-            for (int q = 0; q < NE; ++q) {
-                long x = x0 + t / BK + (256 / BK) * q;
-                x = x < xmax ? x : xmax - 1;
-                xo[q] = imap_eval(mx, x);
-                if (HAS2) xo2[q] = imap_eval(mx2, x);
-            }
-        } else {
-            long x = x0 + t % BX;
-            x = x < xmax ? x : xmax - 1;
-            xo[0] = imap_eval(mx, x);
-            if (HAS2) xo2[0] = imap_eval(mx2, x);
-#pragma unroll
-            for (int q = 0; q < NE; ++q) {
-                kk[q] = t / BX + (256 / BX) * q;
-                kt[q].init(mk, kstart + kk[q]);
-                if (HAS2) kt2[q].init(mk2, kstart + kk[q]);
-            }
-        }
-    }
-
-    // issue the global loads of the tile starting at k0 (values with k >= K read as 0)
-    __device__ __forceinline__ void load(const float* __restrict__ p, const float* __restrict__ p2, long k0,
-                                         long K) {
-#pragma unroll
-        for (int q = 0; q < NE; ++q) {
-            const int ti = KFAST ? 0 : q, xi = KFAST ? q : 0;
-            const bool ok = k0 + kk[ti] < K;
-            float a = ok ? p[xo[xi] + kt[ti].off] : 0.f;
-            if (HAS2) {
-                const float b = ok ? p2[xo2[xi] + kt2[ti].off] : 0.f;
-                a *= b;
-            }
-            v[q] = a;
-        }
-    }
-
-    __device__ __forceinline__ void advance(const IMapD& mk, const IMapD& mk2) {
-#pragma unroll
-        for (int q = 0; q < NT; ++q) {
-            kt[q].step(mk);
-            if (HAS2) kt2[q].step(mk2);
-        }
-    }
-
-    __device__ __forceinline__ void store(float* __restrict__ lds, int t) const {
-#pragma unroll
-        for (int q = 0; q < NE; ++q) {
-            int k, x;
-            if (KFAST) {
-                k = t % BK;
-                x = t / BK + (256 / BK) * q;
-            } else {
-                k = t / BX + (256 / BX) * q;
-                x = t % BX;
-            }
-            lds[k * LDS_STRIDE + x] = v[q];
-        }
-    }
-};
 
 __device__ __forceinline__ float ssp_act(float v, float cst) {
     const float sp = v > 20.f ? v : log1pf(expf(v));
@@ -166,30 +77,212 @@ __device__ __forceinline__ float ssp_grad_from_out(float h, float cst) {
     return cst * (1.f - expf(-sp));
 }
 
-template <int TM, int TN, bool A_KFAST, bool B_KFAST, bool HAS2>
-__global__ __launch_bounds__(256) void tfc_gemm_kernel(const GemmArgs g) {
-    constexpr int BM = 64 * TM, BN = 64 * TN;
-    __shared__ float lds[BK * (BM + 2) + BK * (BN + 2)];
-    float* As = lds;
-    float* Bs = lds + BK * (BM + 2);
+__device__ __forceinline__ float epilogue_apply(const Problem& P, float acc, long o) {
+    float v = P.alpha * acc;
+    if (P.epilogue == TFC_EPI_SSP) v = ssp_act(v, P.act_cst);
+    if (P.epilogue == TFC_EPI_SSP_GRAD) v *= ssp_grad_from_out(P.aux[o], P.act_cst);
+    if (P.accumulate) v += P.c[o];
+    return v;
+}
+
+// One operand tile [BK][BX] loaded by 256 threads.  KFAST: consecutive threads walk k (operand
+// contiguous along k); otherwise they walk x (contiguous along the row / column index).
+// load() only ISSUES the global loads; the product of the two factors and the zeroing of the K
+// tail happen in store(), after the MFMAs of the current tile, so that nothing waits on the loads
+// while they are in flight.
+template <int BX, bool KFAST, bool HAS2, bool VEC>
+struct Operand {
+    static constexpr int NE = BX * BK / 256;  // elements per thread
+    static constexpr int S = BX + 4;          // LDS row stride
+    float v[NE], v2[HAS2 ? NE : 1];
+
+    __device__ __forceinline__ void load(const float* __restrict__ p, const float* __restrict__ p2,
+                                         const long* __restrict__ roff, const long* __restrict__ roff2,
+                                         const long* __restrict__ ko, const long* __restrict__ ko2, int t, bool,
+                                         bool) {
+        if (KFAST) {
+            const int kk = t % BK;
+            const long o = ko[kk];
+            const long o2 = HAS2 ? ko2[kk] : 0;
+#pragma unroll
+            for (int q = 0; q < NE; ++q) {
+                const int x = t / BK + (256 / BK) * q;
+                v[q] = p[roff[x] + o];
+                if (HAS2) v2[q] = p2[roff2[x] + o2];
+            }
+        } else {
+            const int x = t % BX;
+            const long r = roff[x];
+            const long r2 = HAS2 ? roff2[x] : 0;
+#pragma unroll
+            for (int q = 0; q < NE; ++q) {
+                const int kk = t / BX + (256 / BX) * q;
+                v[q] = p[r + ko[kk]];
+                if (HAS2) v2[q] = p2[r2 + ko2[kk]];
+            }
+        }
+    }
+
+    // k_left = K - (first k of the tile): elements with kk >= k_left are stored as 0
+    __device__ __forceinline__ void store(float* __restrict__ lds, int t, int k_left) const {
+#pragma unroll
+        for (int q = 0; q < NE; ++q) {
+            int k, x;
+            if (KFAST) {
+                k = t % BK;
+                x = t / BK + (256 / BK) * q;
+            } else {
+                k = t / BX + (256 / BX) * q;
+                x = t % BX;
+            }
+            float a = v[q];
+            if (HAS2) a *= v2[q];
+            lds[k * S + x] = k < k_left ? a : 0.f;
+        }
+    }
+};
+
+// 16-byte variant: every thread moves groups of 4 elements that are consecutive along the walked
+// index.  Each factor is either contiguous there (one global_load_dwordx4) or constant over the
+// group (`bc`: one dword, replicated).  The host selects this variant only when the maps, the
+// base pointers and the extents guarantee aligned, in-bounds groups (vec_ok()).
+template <int BX, bool KFAST, bool HAS2>
+struct Operand<BX, KFAST, HAS2, true> {
+    static constexpr int NV = BX * BK / 1024;  // groups per thread
+    static constexpr int S = BX + 4;
+    float4 v[NV], v2[HAS2 ? NV : 1];
+
+    static __device__ __forceinline__ float4 fetch(const float* __restrict__ p, bool bc) {
+        if (bc) {
+            const float s = *p;
+            return make_float4(s, s, s, s);
+        }
+        return *reinterpret_cast<const float4*>(p);
+    }
+
+    __device__ __forceinline__ void load(const float* __restrict__ p, const float* __restrict__ p2,
+                                         const long* __restrict__ roff, const long* __restrict__ roff2,
+                                         const long* __restrict__ ko, const long* __restrict__ ko2, int t, bool bc1,
+                                         bool bc2) {
+        if (KFAST) {
+            const int kq = t & 3;  // k = 4 kq .. 4 kq + 3
+            const long o = ko[4 * kq];
+            const long o2 = HAS2 ? ko2[4 * kq] : 0;
+#pragma unroll
+            for (int q = 0; q < NV; ++q) {
+                const int x = (t >> 2) + 64 * q;
+                v[q] = fetch(p + roff[x] + o, bc1);
+                if (HAS2) v2[q] = fetch(p2 + roff2[x] + o2, bc2);
+            }
+        } else {
+            const int xq = t % (BX / 4);  // x = 4 xq .. 4 xq + 3
+            const long r = roff[4 * xq];
+            const long r2 = HAS2 ? roff2[4 * xq] : 0;
+#pragma unroll
+            for (int q = 0; q < NV; ++q) {
+                const int kk = t / (BX / 4) + (1024 / BX) * q;
+                v[q] = fetch(p + r + ko[kk], bc1);
+                if (HAS2) v2[q] = fetch(p2 + r2 + ko2[kk], bc2);
+            }
+        }
+    }
+
+    __device__ __forceinline__ void store(float* __restrict__ lds, int t, int k_left) const {
+#pragma unroll
+        for (int q = 0; q < NV; ++q) {
+            float4 a = v[q];
+            if (HAS2) {
+                a.x *= v2[q].x;
+                a.y *= v2[q].y;
+                a.z *= v2[q].z;
+                a.w *= v2[q].w;
+            }
+            if (KFAST) {
+                const int k = 4 * (t & 3), x = (t >> 2) + 64 * q;
+                lds[(k + 0) * S + x] = k + 0 < k_left ? a.x : 0.f;
+                lds[(k + 1) * S + x] = k + 1 < k_left ? a.y : 0.f;
+                lds[(k + 2) * S + x] = k + 2 < k_left ? a.z : 0.f;
+                lds[(k + 3) * S + x] = k + 3 < k_left ? a.w : 0.f;
+            } else {
+                const int k = t / (BX / 4) + (1024 / BX) * q, x = 4 * (t % (BX / 4));
+                if (k >= k_left) a = make_float4(0.f, 0.f, 0.f, 0.f);
+                *reinterpret_cast<float4*>(&lds[k * S + x]) = a;
+            }
+        }
+    }
+};
+
+template <int TM, int TN, bool A_KFAST, bool B_KFAST, bool HAS2, bool AV, bool BV>
+__global__ __launch_bounds__(256, (TM * TN == 4 ? 4 : 1)) void tfc_gemm_kernel(const Group g) {
+    constexpr int BM = 64 * TM, BN = 64 * TN, SA = BM + 4, SB = BN + 4;
+    constexpr int TILE = BK * SA + BK * SB;
+    __shared__ __attribute__((aligned(16))) float tiles[2 * TILE];
+    __shared__ long roff[3 * BM + BN];  // rows of A1, rows of A2, rows of C, columns of B
+    __shared__ long koff[2][3][KT * BK];  // k offsets of KT tiles at a time (double buffered): A1, A2, B
+    long* roffA = roff;
+    long* roffA2 = roff + BM;
+    long* roffC = roff + 2 * BM;
+    long* roffB = roff + 3 * BM;
 
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int wm = wave >> 1, wn = wave & 1;
-    const long nbm = (g.m + BM - 1) / BM, nbn = (g.n + BN - 1) / BN;
-    const unsigned vb = tfc_xcd_remap(blockIdx.x, gridDim.x);
-    const long tile = vb % (nbm * nbn);
-    const int z = (int)(vb / (nbm * nbn));      // K range of this block
-    const long bm = tile % nbm, bn = tile / nbm;  // consecutive blocks share the B tile
-    const long r0 = bm * BM, j0 = bn * BN;
-    const long nkt_all = (g.k + BK - 1) / BK;
-    const long per = (nkt_all + g.splits - 1) / g.splits;
-    const long kt_begin = z * per;
-    const long kt_end = kt_begin + per < nkt_all ? kt_begin + per : nkt_all;
+    const int vb = (int)tfc_xcd_remap(blockIdx.x, gridDim.x);
+    int pi = 0;
+    for (int i = 1; i < g.n; ++i)
+        if (vb >= g.p[i].block_begin) pi = i;
+    const Problem& P = g.p[pi];
+    // loop invariants out of the kernel-argument segment (a scalar load inside the K loop would
+    // put an lgkmcnt(0) wait, which also drains the LDS queue, into every tile)
+    const float* __restrict__ pa1 = P.a1;
+    const float* __restrict__ pa2 = HAS2 ? P.a2 : P.a1;
+    const float* __restrict__ pb = P.b;
+    const int K = P.k;
+    const Map ka1 = P.a1_k, ka2 = P.a2_k, kb = P.b_k;
+    const bool bc1 = P.a1_bc != 0, bc2 = P.a2_bc != 0;
 
-    Operand<BM, A_KFAST, HAS2> A;
-    Operand<BN, B_KFAST, false> B;
-    A.init(g.a1_r, g.a1_k, g.a2_r, g.a2_k, r0, g.m, t, kt_begin * BK);
-    B.init(g.b_j, g.b_k, g.b_j, g.b_k, j0, g.n, t, kt_begin * BK);
+    const int local = vb - P.block_begin;
+    const int nbm = (P.m + BM - 1) / BM, nbn = (P.n + BN - 1) / BN;
+    const int ntile = nbm * nbn;
+    const int z = local / ntile;  // K range of this block
+    const int tile = local - z * ntile;
+    const int bm = tile % nbm, bn = tile / nbm;  // consecutive blocks share the B tile
+    const int r0 = bm * BM, j0 = bn * BN;
+    const int nkt_all = (P.k + BK - 1) / BK;
+    const int per = (nkt_all + P.splits - 1) / P.splits;
+    const int kt_begin = z * per;
+    const int kt_end = kt_begin + per < nkt_all ? kt_begin + per : nkt_all;
+    const int n_tiles = kt_end - kt_begin;
+
+    // offset tables
+    if (t < BM) {
+        // rows past the end re-read valid ones (never stored); a 16-byte group stays a group
+        const int row = r0 + t < P.m ? r0 + t : ((AV && !A_KFAST) ? P.m - 4 + (t & 3) : P.m - 1);
+        roffA[t] = map_eval(P.a1_r, row);
+        if (HAS2) roffA2[t] = map_eval(P.a2_r, row);
+        roffC[t] = map_eval(P.c_r, r0 + t < P.m ? r0 + t : P.m - 1);
+    }
+    if (t >= 128 && t < 128 + BN) {
+        const int col = j0 + (t - 128) < P.n ? j0 + (t - 128) : ((BV && !B_KFAST) ? P.n - 4 + (t & 3) : P.n - 1);
+        roffB[t - 128] = map_eval(P.b_j, col);
+    }
+    // k offsets: the integer divisions of the maps cost a few hundred cycles, so they are done
+    // for KT tiles at once by 128 threads in parallel (every KT-th iteration), not by 16 threads
+    // in every tile, which would make one wave the straggler of every barrier
+    auto fill_koff = [&](int first_tile) {  // tiles first_tile .. first_tile + KT - 1 (relative)
+        if (t < KT * BK) {
+            const int buf = (first_tile / KT) & 1, kk = t % BK;
+            const int k = (kt_begin + first_tile + t / BK) * BK + kk;
+            int kc_a = k < K ? k : ((AV && A_KFAST) ? K - 4 + (kk & 3) : K - 1);
+            int kc_b = k < K ? k : ((BV && B_KFAST) ? K - 4 + (kk & 3) : K - 1);
+            if (kc_a < 0) kc_a = 0;
+            if (kc_b < 0) kc_b = 0;
+            koff[buf][0][t] = map_eval(ka1, kc_a);
+            if (HAS2) koff[buf][1][t] = map_eval(ka2, kc_a);
+            koff[buf][2][t] = map_eval(kb, kc_b);
+        }
+    };
+    fill_koff(0);
+    __syncthreads();
 
     floatx16 acc[TM][TN];
 #pragma unroll
@@ -199,140 +292,218 @@ __global__ __launch_bounds__(256) void tfc_gemm_kernel(const GemmArgs g) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    const long nkt = kt_end;
-    A.load(g.a1, g.a2, kt_begin * BK, g.k);
-    B.load(g.b, nullptr, kt_begin * BK, g.k);
-    for (long kt = kt_begin; kt < nkt; ++kt) {
-        A.store(As, t);
-        B.store(Bs, t);
-        __syncthreads();
-        if (kt + 1 < nkt) {
-            A.advance(g.a1_k, g.a2_k);
-            B.advance(g.b_k, g.b_k);
-            A.load(g.a1, g.a2, (kt + 1) * BK, g.k);
-            B.load(g.b, nullptr, (kt + 1) * BK, g.k);
+    Operand<BM, A_KFAST, HAS2, AV> A;
+    Operand<BN, B_KFAST, false, BV> B;
+    if (n_tiles > 0) {
+        A.load(pa1, pa2, roffA, roffA2, koff[0][0], koff[0][1], t, bc1, bc2);
+        B.load(pb, nullptr, roffB, nullptr, koff[0][2], nullptr, t, false, false);
+        A.store(tiles, t, K - kt_begin * BK);
+        B.store(tiles + BK * SA, t, K - kt_begin * BK);
+    }
+    __syncthreads();
+
+    const int half = lane >> 5, l31 = lane & 31;
+    for (int i = 0; i < n_tiles; ++i) {
+        const int cur = i & 1, nxt = cur ^ 1;
+        const bool more = i + 1 < n_tiles;
+        if (more) {
+            const int kb_ = ((i + 1) / KT) & 1, ko_ = ((i + 1) % KT) * BK;
+            A.load(pa1, pa2, roffA, roffA2, koff[kb_][0] + ko_, koff[kb_][1] + ko_, t, bc1, bc2);
+            B.load(pb, nullptr, roffB, nullptr, koff[kb_][2] + ko_, nullptr, t, false, false);
         }
-        const int half = lane >> 5, l31 = lane & 31;
+        const float* As = tiles + cur * TILE;
+        const float* Bs = As + BK * SA;
 #pragma unroll
         for (int s = 0; s < BK / 2; ++s) {
             float af[TM], bf[TN];
 #pragma unroll
-            for (int i = 0; i < TM; ++i) af[i] = As[(2 * s + half) * (BM + 2) + wm * 32 * TM + i * 32 + l31];
+            for (int ii = 0; ii < TM; ++ii) af[ii] = As[(2 * s + half) * SA + wm * 32 * TM + ii * 32 + l31];
 #pragma unroll
-            for (int j = 0; j < TN; ++j) bf[j] = Bs[(2 * s + half) * (BN + 2) + wn * 32 * TN + j * 32 + l31];
+            for (int j = 0; j < TN; ++j) bf[j] = Bs[(2 * s + half) * SB + wn * 32 * TN + j * 32 + l31];
 #pragma unroll
-            for (int i = 0; i < TM; ++i)
+            for (int ii = 0; ii < TM; ++ii)
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i], bf[j], acc[i][j], 0, 0, 0);
+                    acc[ii][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[ii], bf[j], acc[ii][j], 0, 0, 0);
+        }
+        // the offsets of tiles i + KT .. replace those of tiles i - KT .. i - 1 (last read before
+        // the previous barrier); they are first read in iteration i + KT - 1
+        if (i % KT == 0 && i + KT < n_tiles) fill_koff(i + KT);
+        if (more) {
+            const int k_left = K - (kt_begin + i + 1) * BK;
+            A.store(tiles + nxt * TILE, t, k_left);
+            B.store(tiles + nxt * TILE + BK * SA, t, k_left);
         }
         __syncthreads();
     }
 
     // epilogue: acc[i][j][reg] is C[row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)][col = lane&31]
-    const int half = lane >> 5, l31 = lane & 31;
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
-        const long col = j0 + wn * 32 * TN + j * 32 + l31;
-        if (col >= g.n) continue;
-        const long co = imap_eval(g.c_j, col);
+        const int col = j0 + wn * 32 * TN + j * 32 + l31;
+        if (col >= P.n) continue;
+        const long co = map_eval(P.c_j, col);
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
 #pragma unroll
             for (int reg = 0; reg < 16; ++reg) {
-                const long row = r0 + wm * 32 * TM + i * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * half;
-                if (row >= g.m) continue;
-                if (g.splits > 1) {
-                    g.slab[((long)z * g.m + row) * g.n + col] = acc[i][j][reg];
-                    continue;
+                const int lr = wm * 32 * TM + i * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * half;
+                const int row = r0 + lr;
+                if (row >= P.m) continue;
+                if (P.splits > 1) {
+                    P.slab[((long)z * P.m + row) * P.n + col] = acc[i][j][reg];
+                } else {
+                    const long o = roffC[lr] + co;
+                    P.c[o] = epilogue_apply(P, acc[i][j][reg], o);
                 }
-                const long o = imap_eval(g.c_r, row) + co;
-                float v = g.alpha * acc[i][j][reg];
-                if (g.epilogue == TFC_EPI_SSP) v = ssp_act(v, g.act_cst);
-                if (g.epilogue == TFC_EPI_SSP_GRAD) v *= ssp_grad_from_out(g.aux[o], g.act_cst);
-                if (g.accumulate) v += g.c[o];
-                g.c[o] = v;
             }
         }
     }
 }
 
 // second stage of split-K: ordered sum of the partial slabs, then the usual epilogue
-__global__ __launch_bounds__(256) void tfc_gemm_reduce_kernel(const GemmArgs g) {
-    const long total = g.m * g.n;
+__global__ __launch_bounds__(256) void tfc_gemm_reduce_kernel(const Group g) {
+    const Problem& P = g.p[blockIdx.y];
+    if (P.splits <= 1) return;
+    const long total = (long)P.m * P.n;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
          i += (long)gridDim.x * blockDim.x) {
-        const long row = i / g.n, col = i - row * g.n;
+        const int row = (int)(i / P.n), col = (int)(i - (long)row * P.n);
         float s = 0.f;
-        for (int z = 0; z < g.splits; ++z) s += g.slab[(long)z * total + i];
-        const long o = imap_eval(g.c_r, row) + imap_eval(g.c_j, col);
-        float v = g.alpha * s;
-        if (g.epilogue == TFC_EPI_SSP) v = ssp_act(v, g.act_cst);
-        if (g.epilogue == TFC_EPI_SSP_GRAD) v *= ssp_grad_from_out(g.aux[o], g.act_cst);
-        if (g.accumulate) v += g.c[o];
-        g.c[o] = v;
+        for (int z = 0; z < P.splits; ++z) s += P.slab[(long)z * total + i];
+        const long o = map_eval(P.c_r, row) + map_eval(P.c_j, col);
+        P.c[o] = epilogue_apply(P, s, o);
     }
 }
 
-int convert_map(const tfc_imap& in, IMapD* out, const char* name) {
+int convert_map(const tfc_imap& in, Map* out, const char* name) {
     TFC_REQUIRE(in.d1 >= 1 && in.d2 >= 1, TFC_EINVAL, "tfc_gemm: map %s has d1=%d d2=%d", name, in.d1, in.d2);
     out->d1 = in.d1;
     out->d2 = in.d2;
     out->s0 = in.s0;
     out->s1 = in.s1;
     out->s2 = in.s2;
-    const int a2 = BK / in.d2;
-    out->b2 = BK % in.d2;
-    const int A1 = a2 / in.d1;
-    out->B1 = a2 % in.d1;
-    out->K0 = (long)out->b2 * in.s2 + (long)out->B1 * in.s1 + (long)A1 * in.s0;
-    out->K2 = in.s1 - (long)in.d2 * in.s2;
-    out->K1 = in.s0 - (long)in.d1 * in.s1;
     return TFC_OK;
 }
 
-long map_unit_step(const tfc_imap& m) {  // f(1) - f(0)
-    if (m.d2 > 1) return m.s2;
-    if (m.d1 > 1) return m.s1;
-    return m.s0;
+long host_map_eval(const tfc_imap& m, long t) {
+    const long q2 = t / m.d2, r2 = t - q2 * m.d2;
+    const long q1 = q2 / m.d1, r1 = q2 - q1 * m.d1;
+    return q1 * m.s0 + r1 * m.s1 + r2 * m.s2;
 }
 
-template <int TM, int TN>
-int launch_tile(const GemmArgs& g, bool a_kfast, bool b_kfast, bool has2, const char* tag, hipStream_t stream) {
-    constexpr int BM = 64 * TM, BN = 64 * TN;
-    const long nb = ((g.m + BM - 1) / BM) * ((g.n + BN - 1) / BN) * g.splits;
-    TFC_REQUIRE(nb < (1LL << 31), TFC_EUNSUPPORTED, "tfc_gemm: grid too large");
-    const dim3 grid((unsigned)nb), block(256);
-    TfcProfScope prof(tag, stream);
-#define TFC_GEMM_LAUNCH(AK, BKF, H2) tfc_gemm_kernel<TM, TN, AK, BKF, H2><<<grid, block, 0, stream>>>(g)
-    if (has2) {
-        if (a_kfast) {
-            if (b_kfast) TFC_GEMM_LAUNCH(true, true, true); else TFC_GEMM_LAUNCH(true, false, true);
-        } else {
-            if (b_kfast) TFC_GEMM_LAUNCH(false, true, true); else TFC_GEMM_LAUNCH(false, false, true);
-        }
+// 128-byte lines one wave-wide load instruction of the staging code touches: 16 k x 4 rows when
+// the threads walk k, 64 rows at one k otherwise (sampled at the origin of the operand)
+int lines_touched(const tfc_imap& r, const tfc_imap& k, long n_rows, long n_k, bool kfast) {
+    long seen[64];
+    int n = 0;
+    auto add = [&](long off) {
+        const long line = off >= 0 ? off >> 5 : -((-off) >> 5) - 1;
+        for (int i = 0; i < n; ++i)
+            if (seen[i] == line) return;
+        seen[n++] = line;
+    };
+    if (kfast) {
+        for (long x = 0; x < std::min<long>(4, n_rows); ++x)
+            for (long kk = 0; kk < std::min<long>(16, n_k); ++kk) add(host_map_eval(r, x) + host_map_eval(k, kk));
     } else {
-        if (a_kfast) {
-            if (b_kfast) TFC_GEMM_LAUNCH(true, true, false); else TFC_GEMM_LAUNCH(true, false, false);
-        } else {
-            if (b_kfast) TFC_GEMM_LAUNCH(false, true, false); else TFC_GEMM_LAUNCH(false, false, false);
-        }
+        for (long x = 0; x < std::min<long>(64, n_rows); ++x) add(host_map_eval(r, x));
     }
-#undef TFC_GEMM_LAUNCH
-    TFC_LAUNCH_CHECK("tfc_gemm_kernel");
-    if (g.splits > 1) {
-        const long total = g.m * g.n;
-        tfc_gemm_reduce_kernel<<<(unsigned)std::min<long>((total + 255) / 256, 4096), 256, 0, stream>>>(g);
-        TFC_LAUNCH_CHECK("tfc_gemm_reduce_kernel");
-    }
-    return TFC_OK;
+    return n;
 }
 
-}  // namespace
+// Stride of the map inside every aligned group of 4 consecutive indices, if it is 0 or 1 there
+// (-1 otherwise).
+int group_stride(const tfc_imap& m) {
+    long s;
+    if (m.d2 > 1) {
+        if (m.d2 % 4) return -1;
+        s = m.s2;
+    } else if (m.d1 > 1) {
+        if (m.d1 % 4) return -1;
+        s = m.s1;
+    } else {
+        s = m.s0;
+    }
+    return s == 0 ? 0 : (s == 1 ? 1 : -1);
+}
 
-extern "C" int tfc_gemm(const tfc_gemm_desc* d, tfc_stream_t stream_) {
-    hipStream_t stream = (hipStream_t)stream_;
-    TFC_REQUIRE(d, TFC_EINVAL, "tfc_gemm: null descriptor");
+// every value of the map at a multiple of `step` (1: any index) is a multiple of 4
+bool offsets_mult4(const tfc_imap& m, long extent, bool fast_unit) {
+    // fast_unit: the innermost active stride is 1 and only group starts (multiples of 4) matter
+    bool inner_done = !fast_unit;
+    if (m.d2 > 1) {
+        if (inner_done && m.s2 % 4) return false;
+        inner_done = true;
+    }
+    if (m.d1 > 1) {
+        if (inner_done && m.s1 % 4) return false;
+        inner_done = true;
+    }
+    if (extent > (long)m.d1 * m.d2 || (m.d1 == 1 && m.d2 == 1)) {
+        if (inner_done && m.s0 % 4) return false;
+    }
+    return true;
+}
+
+// Can one factor (base p, map `fast` along the walked index, `slow` along the other) be staged
+// in 16-byte groups?  *bc = the factor is constant over a group.
+bool factor_vec_ok(const float* p, const tfc_imap& fast, long n_fast, const tfc_imap& slow, long n_slow, int* bc) {
+    const int gs = group_stride(fast);
+    if (gs < 0) return false;
+    *bc = gs == 0;
+    if (gs == 0) return true;
+    return ((uintptr_t)p % 16 == 0) && offsets_mult4(fast, n_fast, true) && offsets_mult4(slow, n_slow, false);
+}
+
+struct Flags {
+    bool a_kfast, b_kfast, has2, av, bv;
+    bool operator==(const Flags& o) const {
+        return a_kfast == o.a_kfast && b_kfast == o.b_kfast && has2 == o.has2 && av == o.av && bv == o.bv;
+    }
+};
+
+// Walk each operand in the order that costs the fewest vector-cache cycles: the staging loads are
+// gathers, so the 128-byte lines a wave's load instruction touches (one per cycle), not the
+// matrix pipe, set the speed when the 64 addresses are spread out; 16-byte loads need a quarter
+// of the instructions.
+Flags flags_of(const tfc_gemm_desc& d, int* a1_bc, int* a2_bc) {
+    Flags f;
+    f.has2 = d.a2 != nullptr;
+    int cost[2];
+    bool vec[2];
+    int bc1[2] = {0, 0}, bc2[2] = {0, 0};
+    for (int kf = 0; kf < 2; ++kf) {
+        const tfc_imap& fast1 = kf ? d.a1_k : d.a1_r;
+        const tfc_imap& slow1 = kf ? d.a1_r : d.a1_k;
+        const long nf = kf ? d.k : d.m, ns = kf ? d.m : d.k;
+        int lines = lines_touched(d.a1_r, d.a1_k, d.m, d.k, kf);
+        bool ok = nf >= 4 && nf % 4 == 0 && factor_vec_ok(d.a1, fast1, nf, slow1, ns, &bc1[kf]);
+        if (f.has2) {
+            lines += lines_touched(d.a2_r, d.a2_k, d.m, d.k, kf);
+            ok = ok && factor_vec_ok(d.a2, kf ? d.a2_k : d.a2_r, nf, kf ? d.a2_r : d.a2_k, ns, &bc2[kf]);
+        }
+        vec[kf] = ok;
+        cost[kf] = lines * (ok ? 1 : 3);
+    }
+    f.a_kfast = cost[1] <= cost[0];
+    f.av = vec[f.a_kfast];
+    *a1_bc = bc1[f.a_kfast];
+    *a2_bc = f.has2 ? bc2[f.a_kfast] : 0;
+    for (int kf = 0; kf < 2; ++kf) {
+        const long nf = kf ? d.k : d.n, ns = kf ? d.n : d.k;
+        int bc = 0;
+        const bool ok = nf >= 4 && nf % 4 == 0 &&
+                        factor_vec_ok(d.b, kf ? d.b_k : d.b_j, nf, kf ? d.b_j : d.b_k, ns, &bc) && !bc;
+        vec[kf] = ok;
+        cost[kf] = lines_touched(d.b_j, d.b_k, d.n, d.k, kf) * (ok ? 1 : 3);
+    }
+    f.b_kfast = cost[1] < cost[0];
+    f.bv = vec[f.b_kfast];
+    return f;
+}
+
+int validate(const tfc_gemm_desc* d) {
     TFC_REQUIRE(d->m >= 0 && d->n >= 0 && d->k >= 0, TFC_EINVAL, "tfc_gemm: negative size");
     TFC_REQUIRE(d->m < (1LL << 31) && d->n < (1LL << 31) && d->k < (1LL << 31), TFC_EUNSUPPORTED,
                 "tfc_gemm: dimension >= 2^31");
@@ -342,69 +513,194 @@ extern "C" int tfc_gemm(const tfc_gemm_desc* d, tfc_stream_t stream_) {
     TFC_REQUIRE(d->epilogue >= TFC_EPI_NONE && d->epilogue <= TFC_EPI_SSP_GRAD, TFC_EINVAL,
                 "tfc_gemm: unknown epilogue %d", d->epilogue);
     TFC_REQUIRE(d->epilogue != TFC_EPI_SSP_GRAD || d->aux, TFC_EINVAL, "tfc_gemm: SSP_GRAD needs aux");
-    GemmArgs g;
-    g.m = d->m;
-    g.n = d->n;
-    g.k = d->k;
-    g.a1 = d->a1;
-    g.a2 = d->a2;
-    g.b = d->b;
-    g.c = d->c;
-    g.aux = d->aux;
-    g.alpha = d->alpha;
-    g.act_cst = d->act_cst;
-    g.accumulate = d->accumulate;
-    g.epilogue = d->epilogue;
+    return TFC_OK;
+}
+
+int convert(const tfc_gemm_desc* d, Problem* p) {
+    p->a1 = d->a1;
+    p->a2 = d->a2;
+    p->b = d->b;
+    p->c = d->c;
+    p->aux = d->aux;
+    p->slab = nullptr;
+    p->m = (int)d->m;
+    p->n = (int)d->n;
+    p->k = (int)d->k;
+    p->splits = 1;
+    p->block_begin = 0;
+    p->alpha = d->alpha;
+    p->act_cst = d->act_cst;
+    p->accumulate = d->accumulate;
+    p->epilogue = d->epilogue;
+    p->a1_bc = p->a2_bc = 0;
     int rc;
-    if ((rc = convert_map(d->a1_r, &g.a1_r, "a1_r"))) return rc;
-    if ((rc = convert_map(d->a1_k, &g.a1_k, "a1_k"))) return rc;
+    if ((rc = convert_map(d->a1_r, &p->a1_r, "a1_r"))) return rc;
+    if ((rc = convert_map(d->a1_k, &p->a1_k, "a1_k"))) return rc;
     if (d->a2) {
-        if ((rc = convert_map(d->a2_r, &g.a2_r, "a2_r"))) return rc;
-        if ((rc = convert_map(d->a2_k, &g.a2_k, "a2_k"))) return rc;
+        if ((rc = convert_map(d->a2_r, &p->a2_r, "a2_r"))) return rc;
+        if ((rc = convert_map(d->a2_k, &p->a2_k, "a2_k"))) return rc;
     } else {
-        g.a2_r = g.a1_r;
-        g.a2_k = g.a1_k;
+        p->a2_r = p->a1_r;
+        p->a2_k = p->a1_k;
     }
-    if ((rc = convert_map(d->b_k, &g.b_k, "b_k"))) return rc;
-    if ((rc = convert_map(d->b_j, &g.b_j, "b_j"))) return rc;
-    if ((rc = convert_map(d->c_r, &g.c_r, "c_r"))) return rc;
-    if ((rc = convert_map(d->c_j, &g.c_j, "c_j"))) return rc;
+    if ((rc = convert_map(d->b_k, &p->b_k, "b_k"))) return rc;
+    if ((rc = convert_map(d->b_j, &p->b_j, "b_j"))) return rc;
+    if ((rc = convert_map(d->c_r, &p->c_r, "c_r"))) return rc;
+    if ((rc = convert_map(d->c_j, &p->c_j, "c_j"))) return rc;
+    return TFC_OK;
+}
 
-    // walk each operand along the index that is contiguous in memory
-    const bool a_kfast = !(map_unit_step(d->a1_r) == 1 && map_unit_step(d->a1_k) != 1);
-    const bool b_kfast = (map_unit_step(d->b_k) == 1 && map_unit_step(d->b_j) != 1);
-    const bool has2 = d->a2 != nullptr;
+inline long cdiv(long a, long b) { return (a + b - 1) / b; }
 
-    const char* tag = d->tag ? d->tag : "tfc_gemm_kernel";
-    g.splits = 1;
-    g.slab = nullptr;
-    // tile: large where the problem fills the chip, small otherwise
-    const long b22 = ((d->m + 127) / 128) * ((d->n + 127) / 128);
-    if (d->n > 64 && d->m > 64 && b22 >= 256) return launch_tile<2, 2>(g, a_kfast, b_kfast, has2, tag, stream);
-    if (d->n <= 64 && d->m > 64 && ((d->m + 127) / 128) >= 256)
-        return launch_tile<2, 1>(g, a_kfast, b_kfast, has2, tag, stream);
-    // small grids with a long K: cut K so that the chip is filled (deterministic: partial tiles
-    // go to the caller's workspace and are summed in a fixed order)
-    const long b11 = ((d->m + 63) / 64) * ((d->n + 63) / 64);
-    const long nkt = (d->k + BK - 1) / BK;
-    if (b11 < 256 && nkt >= 16 && d->workspace) {
-        long splits = std::min<long>((512 + b11 - 1) / b11, nkt / 8);
-        splits = std::min<long>(splits, d->workspace_floats / std::max<long>(d->m * d->n, 1));
-        if (splits > 1) {
-            const long per = (nkt + splits - 1) / splits;
-            splits = (nkt + per - 1) / per;  // no empty range
-            g.splits = (int)splits;
-            g.slab = d->workspace;
+template <int TM, int TN, bool... B>
+void dispatch(const Group& g, dim3 grid, hipStream_t stream) {
+    tfc_gemm_kernel<TM, TN, B...><<<grid, dim3(256), 0, stream>>>(g);
+}
+template <int TM, int TN, bool... B, typename... Rest>
+void dispatch(const Group& g, dim3 grid, hipStream_t stream, bool first, Rest... rest) {
+    if (first)
+        dispatch<TM, TN, B..., true>(g, grid, stream, rest...);
+    else
+        dispatch<TM, TN, B..., false>(g, grid, stream, rest...);
+}
+
+template <int TM, int TN>
+int launch_tile(Group& g, const Flags& f, const char* tag, hipStream_t stream) {
+    constexpr int BM = 64 * TM, BN = 64 * TN;
+    long nb = 0;
+    bool any_split = false;
+    for (int i = 0; i < g.n; ++i) {
+        g.p[i].block_begin = (int)nb;
+        nb += cdiv(g.p[i].m, BM) * cdiv(g.p[i].n, BN) * g.p[i].splits;
+        any_split |= g.p[i].splits > 1;
+        TFC_REQUIRE(nb < (1LL << 31), TFC_EUNSUPPORTED, "tfc_gemm: grid too large");
+    }
+    const dim3 grid((unsigned)nb), block(256);
+    TfcProfScope prof(tag, stream);
+    dispatch<TM, TN>(g, grid, stream, f.a_kfast, f.b_kfast, f.has2, f.av, f.bv);
+    TFC_LAUNCH_CHECK("tfc_gemm_kernel");
+    if (any_split) {
+        long big = 1;
+        for (int i = 0; i < g.n; ++i)
+            if (g.p[i].splits > 1) big = std::max(big, (long)g.p[i].m * g.p[i].n);
+        const dim3 rgrid((unsigned)std::min<long>(cdiv(big, 256), 1024), (unsigned)g.n);
+        tfc_gemm_reduce_kernel<<<rgrid, block, 0, stream>>>(g);
+        TFC_LAUNCH_CHECK("tfc_gemm_reduce_kernel");
+    }
+    return TFC_OK;
+}
+
+// Upper bound on the K ranges a problem may be cut into: ranges of at least 8 K tiles, at most
+// 64 of them, and at most 2^24 floats (64 MiB) of partial tiles.
+long max_splits(long m, long n, long k) {
+    const long nkt = cdiv(k, BK);
+    if (nkt < 16) return 1;
+    const long mn = std::max<long>(m * n, 1);
+    return std::max<long>(1, std::min<long>(std::min<long>(nkt / 8, 64), (1L << 24) / mn));
+}
+
+// one launch: problems with equal operand walking order, at most MAXP of them
+int launch_group(Group& g, const Flags& f, float* workspace, long workspace_floats, const char* tag,
+                 hipStream_t stream) {
+    // tile: the largest one that still fills the chip (counting the K ranges a problem can be cut
+    // into) and does not pad the problems much (a
+    // 128-wide tile on a 64-column problem would spend half its MFMAs on padding)
+    const int cand[3][2] = {{128, 128}, {128, 64}, {64, 64}};
+    long blocks[3], padded[3];
+    for (int c = 0; c < 3; ++c) {
+        blocks[c] = padded[c] = 0;
+        for (int i = 0; i < g.n; ++i) {
+            const long tiles = cdiv(g.p[i].m, cand[c][0]) * cdiv(g.p[i].n, cand[c][1]);
+            blocks[c] += tiles * (workspace ? max_splits(g.p[i].m, g.p[i].n, g.p[i].k) : 1);
+            padded[c] += tiles * cand[c][0] * cand[c][1] * cdiv(g.p[i].k, BK);
         }
     }
-    return launch_tile<1, 1>(g, a_kfast, b_kfast, has2, tag, stream);
+    int pick = 2;
+    for (int c = 1; c >= 0; --c)
+        if (blocks[c] >= 256 && padded[c] * 100 <= padded[2] * 112) pick = c;
+    const int bm = cand[pick][0], bn = cand[pick][1];
+    // K ranges.  All blocks of a launch should carry a similar number of K tiles (the problems of
+    // a group differ in K by up to 2 l + 1 and in the number of tiles by more), and a launch with
+    // few tiles and a long K must still fill the chip: cut every problem into ranges of at most
+    // `len` K tiles, where `len` spreads the launch's work over ~4 blocks per CU.  Deterministic:
+    // partial tiles go to the caller's workspace and are summed in a fixed order.
+    if (workspace) {
+        long work = 0;
+        for (int i = 0; i < g.n; ++i)
+            work += cdiv(g.p[i].m, bm) * cdiv(g.p[i].n, bn) * cdiv(g.p[i].k, BK);
+        const long len = std::max<long>(8, cdiv(work, 1024));
+        long used = 0;
+        for (int i = 0; i < g.n; ++i) {
+            Problem& p = g.p[i];
+            const long nkt = cdiv(p.k, BK);
+            const long mn = std::max<long>((long)p.m * p.n, 1);
+            long splits = std::min<long>(cdiv(nkt, len), max_splits(p.m, p.n, p.k));
+            splits = std::min<long>(splits, (workspace_floats - used) / mn);
+            if (splits > 1) splits = cdiv(nkt, cdiv(nkt, splits));  // no empty range
+            if (splits > 1) {
+                p.splits = (int)splits;
+                p.slab = workspace + used;
+                used += splits * mn;
+            }
+        }
+    }
+    if (bm == 128 && bn == 128) return launch_tile<2, 2>(g, f, tag, stream);
+    if (bm == 128) return launch_tile<2, 1>(g, f, tag, stream);
+    return launch_tile<1, 1>(g, f, tag, stream);
+}
+
+}  // namespace
+
+extern "C" int tfc_gemm_group(const tfc_gemm_desc* descs, int32_t n_descs, tfc_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    TFC_REQUIRE(n_descs >= 0, TFC_EINVAL, "tfc_gemm_group: negative count");
+    if (n_descs == 0) return TFC_OK;
+    TFC_REQUIRE(descs, TFC_EINVAL, "tfc_gemm_group: null descriptors");
+    for (int i = 0; i < n_descs; ++i) {
+        const int rc = validate(&descs[i]);
+        if (rc) return rc;
+    }
+    // launches: runs of problems (in the given order) that walk their operands the same way
+    std::vector<char> done(n_descs, 0);
+    for (int first = 0; first < n_descs; ++first) {
+        if (done[first]) continue;
+        if (descs[first].m == 0 || descs[first].n == 0) {
+            done[first] = 1;
+            continue;
+        }
+        int bc1 = 0, bc2 = 0;
+        const Flags f = flags_of(descs[first], &bc1, &bc2);
+        Group g;
+        g.n = 0;
+        float* ws = nullptr;
+        long ws_floats = 0;
+        const char* tag = descs[first].tag ? descs[first].tag : "tfc_gemm_kernel";
+        for (int i = first; i < n_descs && g.n < MAXP; ++i) {
+            if (done[i] || descs[i].m == 0 || descs[i].n == 0 || !(flags_of(descs[i], &bc1, &bc2) == f)) continue;
+            const int rc = convert(&descs[i], &g.p[g.n]);
+            if (rc) return rc;
+            g.p[g.n].a1_bc = bc1;
+            g.p[g.n].a2_bc = bc2;
+            if (descs[i].workspace && descs[i].workspace_floats > ws_floats) {
+                ws = descs[i].workspace;
+                ws_floats = descs[i].workspace_floats;
+            }
+            done[i] = 1;
+            ++g.n;
+        }
+        const int rc = launch_group(g, f, ws, ws_floats, tag, stream);
+        if (rc) return rc;
+    }
+    return TFC_OK;
+}
+
+extern "C" int tfc_gemm(const tfc_gemm_desc* d, tfc_stream_t stream) {
+    TFC_REQUIRE(d, TFC_EINVAL, "tfc_gemm: null descriptor");
+    return tfc_gemm_group(d, 1, stream);
 }
 
 extern "C" int64_t tfc_gemm_workspace_floats(int64_t m, int64_t n, int64_t k) {
     if (m <= 0 || n <= 0 || k <= 0) return 0;
-    const long b11 = ((m + 63) / 64) * ((n + 63) / 64);
-    const long nkt = (k + BK - 1) / BK;
-    if (b11 >= 256 || nkt < 16) return 0;
-    const long splits = std::min<long>((512 + b11 - 1) / b11, nkt / 8);
+    const long splits = max_splits(m, n, k);
     return splits > 1 ? splits * m * n : 0;
 }

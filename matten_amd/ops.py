@@ -457,13 +457,9 @@ def _gemm_workspace(n_floats: int) -> torch.Tensor:
     return ws
 
 
-def _gemm(m, n, k, a1, b, c, a1_r, a1_k, b_k, b_j, c_r, c_j, alpha=1.0, accumulate=False, a2=None, a2_r=None, a2_k=None,
-          epilogue=_lib.EPI_NONE, aux=None, act_cst=1.0, tag=None):
+def _desc(m, n, k, a1, b, c, a1_r, a1_k, b_k, b_j, c_r, c_j, alpha=1.0, accumulate=False, a2=None, a2_r=None, a2_k=None,
+          epilogue=_lib.EPI_NONE, aux=None, act_cst=1.0, tag=None) -> GemmDesc:
     d = GemmDesc()
-    need = int(_lib.lib().tfc_gemm_workspace_floats(int(m), int(n), int(k)))
-    if need > 0:
-        ws = _gemm_workspace(need)
-        d.workspace, d.workspace_floats = ws.data_ptr(), ws.numel()
     d.tag = tag
     d.m, d.n, d.k = int(m), int(n), int(k)
     d.a1, d.b, d.c = a1, b, c
@@ -477,7 +473,41 @@ def _gemm(m, n, k, a1, b, c, a1_r, a1_k, b_k, b_j, c_r, c_j, alpha=1.0, accumula
     d.epilogue = int(epilogue)
     d.aux = aux
     d.act_cst = float(act_cst)
-    _lib.check(_lib.lib().tfc_gemm(C.byref(d), _stream()))
+    return d
+
+
+def _gemm(*args, **kwargs):
+    """One problem, launched now."""
+    _gemm_group([_desc(*args, **kwargs)])
+
+
+def _gemm_group(descs: "List[GemmDesc]"):
+    """Independent problems (disjoint outputs) in as few launches as possible (tfc_gemm_group)."""
+    if not descs:
+        return
+    L = _lib.lib()
+    need = sum(int(L.tfc_gemm_workspace_floats(d.m, d.n, d.k)) for d in descs)
+    arr = (GemmDesc * len(descs))(*descs)
+    if need > 0:
+        ws = _gemm_workspace(need)
+        for d in arr:
+            d.workspace, d.workspace_floats = ws.data_ptr(), ws.numel()
+    _lib.check(L.tfc_gemm_group(arr, len(descs), _stream()))
+
+
+def _gemm_waves(items):
+    """items: (output key, desc factory taking `accumulate`).  Problems that write the same output
+    block must not share a launch: the n-th writer of a block goes to the n-th group."""
+    waves: "List[List[GemmDesc]]" = []
+    count = {}
+    for key, make in items:
+        w = count.get(key, 0)
+        count[key] = w + 1
+        while len(waves) <= w:
+            waves.append([])
+        waves[w].append(make(w > 0))
+    for group in waves:
+        _gemm_group(group)
 
 
 def _p(t: torch.Tensor, off: int = 0):
@@ -508,15 +538,15 @@ class _LinearFn(torch.autograd.Function):
             raise ValueError(f"linear: x{tuple(x.shape)} / weight[{weight.numel()}] do not match the irreps ({spec.d_in}, {spec.weight_numel})")
         alloc = torch.empty if spec.out_covered else torch.zeros
         out = alloc(n, spec.d_out, dtype=torch.float32, device=x.device)
-        seen = set()
-        for in_off, mi, out_off, mo, d, w_off, pw in spec.instructions:
-            _gemm(
+        def fwd(in_off, mi, out_off, mo, d, w_off, pw):
+            return lambda acc: _desc(
                 n * d, mo, mi, _p(x, in_off), _p(weight, w_off), _p(out, out_off),
                 a1_r=_imap(1, d, spec.d_in, 0, 1), a1_k=_lin(d), b_k=_lin(mo), b_j=_lin(1),
-                c_r=_imap(1, d, spec.d_out, 0, 1), c_j=_lin(d), alpha=pw, accumulate=out_off in seen,
+                c_r=_imap(1, d, spec.d_out, 0, 1), c_j=_lin(d), alpha=pw, accumulate=acc,
                 tag=b"gemm_linear_fwd",
             )
-            seen.add(out_off)
+
+        _gemm_waves([(ins[2], fwd(*ins)) for ins in spec.instructions])
         ctx.save_for_backward(x, weight)
         ctx.spec = spec
         return out
@@ -531,23 +561,26 @@ class _LinearFn(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             alloc = torch.empty if spec.in_covered else torch.zeros
             dx = alloc(n, spec.d_in, dtype=torch.float32, device=x.device)
-            seen = set()
-            for in_off, mi, out_off, mo, d, w_off, pw in spec.instructions:
-                _gemm(
+
+            def bdx(in_off, mi, out_off, mo, d, w_off, pw):
+                return lambda acc: _desc(
                     n * d, mi, mo, _p(g, out_off), _p(weight, w_off), _p(dx, in_off),
                     a1_r=_imap(1, d, spec.d_out, 0, 1), a1_k=_lin(d), b_k=_lin(1), b_j=_lin(mo),
-                    c_r=_imap(1, d, spec.d_in, 0, 1), c_j=_lin(d), alpha=pw, accumulate=in_off in seen,
+                    c_r=_imap(1, d, spec.d_in, 0, 1), c_j=_lin(d), alpha=pw, accumulate=acc,
                     tag=b"gemm_linear_dx",
                 )
-                seen.add(in_off)
+
+            _gemm_waves([(ins[0], bdx(*ins)) for ins in spec.instructions])
         if ctx.needs_input_grad[1]:
             dw = torch.empty_like(weight)
-            for in_off, mi, out_off, mo, d, w_off, pw in spec.instructions:
-                _gemm(
+            _gemm_group([
+                _desc(
                     mi, mo, n * d, _p(x, in_off), _p(g, out_off), _p(dw, w_off),
                     a1_r=_lin(d), a1_k=_imap(1, d, spec.d_in, 0, 1), b_k=_imap(1, d, spec.d_out, 0, 1), b_j=_lin(d),
                     c_r=_lin(mo), c_j=_lin(1), alpha=pw, tag=b"gemm_linear_dw",
                 )
+                for in_off, mi, out_off, mo, d, w_off, pw in spec.instructions
+            ])
         return dx, dw, None
 
 
@@ -649,21 +682,22 @@ class _FctpFn(torch.autograd.Function):
                 raise ValueError("fctp: `base` must be a contiguous [N, d_out] tensor")
             out = base
             ctx.mark_dirty(base)
-            seen = None
+            on_base = True
         else:
             alloc = torch.empty if spec.out_covered else torch.zeros
             out = alloc(n, spec.d_out, dtype=torch.float32, device=x.device)
-            seen = set()
-        for xo, mu, ao, mv, oo, mw, d, wo, alpha in spec.instructions:
-            _gemm(
+            on_base = False
+
+        def fwd(xo, mu, ao, mv, oo, mw, d, wo, alpha):
+            return lambda acc: _desc(
                 n * d, mw, mu * mv, _p(x, xo), _p(weight, wo), _p(out, oo),
                 a1_r=_imap(1, d, spec.d_x, 0, 1), a1_k=_imap(1, mv, d, 0, 0),
                 a2=_p(a, ao), a2_r=_imap(1, d, spec.d_a, 0, 0), a2_k=_imap(1, mv, 0, 0, 1),
                 b_k=_lin(mw), b_j=_lin(1), c_r=_imap(1, d, spec.d_out, 0, 1), c_j=_lin(d), alpha=alpha,
-                accumulate=True if seen is None else (oo in seen), tag=b"gemm_fctp_fwd",
+                accumulate=acc or on_base, tag=b"gemm_fctp_fwd",
             )
-            if seen is not None:
-                seen.add(oo)
+
+        _gemm_waves([(ins[4], fwd(*ins)) for ins in spec.instructions])
         ctx.save_for_backward(x, a, weight)
         ctx.spec = spec
         ctx.has_base = base is not None
@@ -678,41 +712,50 @@ class _FctpFn(torch.autograd.Function):
         dx = da = dw = None
         if ctx.needs_input_grad[0]:
             dx = (torch.empty if spec.x_covered else torch.zeros)(n, spec.d_x, dtype=torch.float32, device=x.device)
-            seen = set()
-            for xo, mu, ao, mv, oo, mw, d, wo, alpha in spec.instructions:
+
+            def bdx(xo, mu, ao, mv, oo, mw, d, wo, alpha):
                 # dx[(n,k), u] = sum_{(v,w)} a[n,v] g[n,w,k] W[u,v,w]
-                _gemm(
+                return lambda acc: _desc(
                     n * d, mu, mv * mw, _p(a, ao), _p(weight, wo), _p(dx, xo),
                     a1_r=_imap(1, d, spec.d_a, 0, 0), a1_k=_imap(1, mw, 1, 0, 0),
                     a2=_p(g, oo), a2_r=_imap(1, d, spec.d_out, 0, 1), a2_k=_imap(1, mw, 0, 0, d),
                     b_k=_lin(1), b_j=_lin(mv * mw), c_r=_imap(1, d, spec.d_x, 0, 1), c_j=_lin(d), alpha=alpha,
-                    accumulate=xo in seen, tag=b"gemm_fctp_dx",
+                    accumulate=acc, tag=b"gemm_fctp_dx",
                 )
-                seen.add(xo)
+
+            _gemm_waves([(ins[0], bdx(*ins)) for ins in spec.instructions])
         if ctx.needs_input_grad[1]:
-            da = (torch.empty if spec.a_covered else torch.zeros)(n, spec.d_a, dtype=torch.float32, device=x.device)
-            seen = set()
-            for xo, mu, ao, mv, oo, mw, d, wo, alpha in spec.instructions:
-                # da[n, v] = sum_{(u,w,k)} x[n,u,k] g[n,w,k] W[u,v,w]
-                _gemm(
-                    n, mv, mu * mw * d, _p(x, xo), _p(weight, wo), _p(da, ao),
+            # da[n, v] = sum_{(u,w,k)} x[n,u,k] g[n,w,k] W[u,v,w].  Every instruction adds to the same
+            # block of `da`: each writes its own partial [N, mul_v] in one grouped launch, and the
+            # partials are then summed in instruction order (deterministic).
+            ni = len(spec.instructions)
+            part = torch.empty(ni, n, spec.d_a, dtype=torch.float32, device=x.device)
+            if not spec.a_covered or any(ins[3] != spec.d_a for ins in spec.instructions):
+                part.zero_()
+            _gemm_group([
+                _desc(
+                    n, mv, mu * mw * d, _p(x, xo), _p(weight, wo), _p(part, i * n * spec.d_a + ao),
                     a1_r=_lin(spec.d_x), a1_k=_imap(mw, d, d, 0, 1),
                     a2=_p(g, oo), a2_r=_lin(spec.d_out), a2_k=_imap(mw, d, 0, d, 1),
                     b_k=_imap(mw, d, mv * mw, 1, 0), b_j=_lin(mw), c_r=_lin(spec.d_a), c_j=_lin(1), alpha=alpha,
-                    accumulate=ao in seen, tag=b"gemm_fctp_da",
+                    tag=b"gemm_fctp_da",
                 )
-                seen.add(ao)
+                for i, (xo, mu, ao, mv, oo, mw, d, wo, alpha) in enumerate(spec.instructions)
+            ])
+            da = part.sum(dim=0) if ni > 1 else part[0]
         if ctx.needs_input_grad[2]:
             dw = torch.empty_like(weight)
-            for xo, mu, ao, mv, oo, mw, d, wo, alpha in spec.instructions:
-                # dW[(u,v), w] = sum_{(n,k)} x[n,u,k] a[n,v] g[n,w,k]
-                _gemm(
+            # dW[(u,v), w] = sum_{(n,k)} x[n,u,k] a[n,v] g[n,w,k]
+            _gemm_group([
+                _desc(
                     mu * mv, mw, n * d, _p(x, xo), _p(g, oo), _p(dw, wo),
                     a1_r=_imap(1, mv, d, 0, 0), a1_k=_imap(1, d, spec.d_x, 0, 1),
                     a2=_p(a, ao), a2_r=_imap(1, mv, 0, 0, 1), a2_k=_imap(1, d, spec.d_a, 0, 0),
                     b_k=_imap(1, d, spec.d_out, 0, 1), b_j=_lin(d), c_r=_lin(mw), c_j=_lin(1), alpha=alpha,
                     tag=b"gemm_fctp_dw",
                 )
+                for xo, mu, ao, mv, oo, mw, d, wo, alpha in spec.instructions
+            ])
         return dx, da, dw, None, (g if ctx.has_base else None)
 
 
