@@ -60,6 +60,7 @@ struct tfc_conv_plan {
     int msz;  // floats per edge of the M buffer (multiple of 4)
     int py;   // floats per edge of the partial-dy buffer
     int n_fwd_items, n_bwd_items;
+    int lmax;  // largest l1, l2 or l3 of any path
     int device;
     PathDev* paths;
     FwdItem* fwd_items;
@@ -97,17 +98,19 @@ __global__ __launch_bounds__(256) void tfc_m_prepass_kernel(const float* __restr
 // ------------------------------------------------------------------------------------------
 // Forward
 // ------------------------------------------------------------------------------------------
+// UNR edges of one path: all gathers first, then the FMAs.  The ids of up to 64 edges of the node
+// sit in one VGPR each (lane j = edge c0 + j, loaded with one vector load) and are read out with
+// v_readlane, so that no step waits on a scalar load of its own.
 template <int L1, int L3, int UNR>
 __device__ __forceinline__ void fwd_edges(const float* __restrict__ xb, const float* __restrict__ wb,
-                                          const float* __restrict__ Mb, const int* __restrict__ eid,
-                                          const int* __restrict__ nbr, int k, int d_in, int w_numel,
-                                          int msz, float (&acc)[2 * L3 + 1]) {
+                                          const float* __restrict__ Mb, int ev, int sv, int j0, int k,
+                                          int d_in, int w_numel, int msz, float (&acc)[2 * L3 + 1]) {
     constexpr int D1 = 2 * L1 + 1, D3 = 2 * L3 + 1;
     float xv[UNR][D1], wv[UNR];
 #pragma unroll
     for (int j = 0; j < UNR; ++j) {
-        const int e = eid[k + j];
-        const int s = nbr[k + j];
+        const int e = __builtin_amdgcn_readlane(ev, j0 + j);
+        const int s = __builtin_amdgcn_readlane(sv, j0 + j);
         const float* xr = xb + (size_t)s * d_in;
 #pragma unroll
         for (int m1 = 0; m1 < D1; ++m1) xv[j][m1] = xr[m1];
@@ -133,6 +136,8 @@ __device__ __forceinline__ void fwd_item(const float* __restrict__ x, const floa
                                          int u, bool active, int node, int d_in, int d_out, int w_numel,
                                          int msz, float scale, float* __restrict__ out) {
     constexpr int D1 = 2 * L1 + 1, D3 = 2 * L3 + 1;
+    constexpr int UNR = D1 <= 3 ? 8 : 4;
+    const int lane = threadIdx.x & 63;
     const int uu = active ? u : 0;  // idle lanes shadow channel 0: valid addresses, nothing stored
     const float* xb = x + p.x_off + uu * D1;
     const float* wb = w + p.w_off + uu;
@@ -140,9 +145,14 @@ __device__ __forceinline__ void fwd_item(const float* __restrict__ x, const floa
     float acc[D3];
 #pragma unroll
     for (int m3 = 0; m3 < D3; ++m3) acc[m3] = 0.f;
-    int k = beg;
-    for (; k + 4 <= end; k += 4) fwd_edges<L1, L3, 4>(xb, wb, Mb, eid, nbr, k, d_in, w_numel, msz, acc);
-    for (; k < end; ++k) fwd_edges<L1, L3, 1>(xb, wb, Mb, eid, nbr, k, d_in, w_numel, msz, acc);
+    for (int c0 = beg; c0 < end; c0 += 64) {
+        const int cn = end - c0 < 64 ? end - c0 : 64;
+        const int kl = c0 + (lane < cn ? lane : cn - 1);
+        const int ev = eid[kl], sv = nbr[kl];
+        int j = 0;
+        for (; j + UNR <= cn; j += UNR) fwd_edges<L1, L3, UNR>(xb, wb, Mb, ev, sv, j, c0 + j, d_in, w_numel, msz, acc);
+        for (; j < cn; ++j) fwd_edges<L1, L3, 1>(xb, wb, Mb, ev, sv, j, c0 + j, d_in, w_numel, msz, acc);
+    }
     if (active) {
         const float cs = p.coeff * scale;
         float* o = out + (size_t)node * d_out + p.out_off + u * D3;
@@ -189,6 +199,15 @@ __global__ __launch_bounds__(256) void tfc_conv_fwd_kernel(
 // Backward.  Centre node = sender: its own row x[n] is fixed for the whole item, the upstream
 // gradient rows gout[receiver] are gathered.
 // ------------------------------------------------------------------------------------------
+// U edges of one path per step: all their gathers are issued before the first use, and the
+// 64-lane sums the edge-attribute gradient needs (one per edge and m2) are taken U * (2 l2 + 1)
+// at a time by the reduce-scatter butterfly of tfc_common.h instead of one at a time.
+template <int D2>
+struct BwdUnroll {
+    static constexpr int U = D2 == 1 ? 4 : (D2 == 3 ? 5 : (D2 == 5 ? 3 : 2));  // U * D2 <= 16
+    static constexpr int V = D2 == 1 ? 4 : 16;
+};
+
 template <int L1, int L2, int L3, bool NEED_DY>
 __device__ __forceinline__ void bwd_path(const float* __restrict__ w, const float* __restrict__ gout,
                                          const float* __restrict__ M, const float* __restrict__ cgd,
@@ -198,6 +217,9 @@ __device__ __forceinline__ void bwd_path(const float* __restrict__ w, const floa
                                          const float (&xv)[2 * L1 + 1], float (&gx)[2 * L1 + 1],
                                          float* __restrict__ dw, float* __restrict__ dyp, int chunk) {
     constexpr int D1 = 2 * L1 + 1, D2 = 2 * L2 + 1, D3 = 2 * L3 + 1;
+    constexpr int U = NEED_DY ? BwdUnroll<D2>::U : 4;
+    constexpr int V = BwdUnroll<D2>::V;
+    const int lane = threadIdx.x & 63;
     const float cs = p.coeff * scale;
     const float* gb = gout + p.out_off + uu * D3;
     const float* wb = w + p.w_off + uu;
@@ -218,41 +240,75 @@ __device__ __forceinline__ void bwd_path(const float* __restrict__ w, const floa
                 P[m2][m3] = active ? s : 0.f;
             }
     }
+    // which reduced value this lane ends up holding, and the edge / component it belongs to
+    const int ridx = V == 16 ? tfc_reduce16_index(lane) : tfc_reduce4_index(lane);
+    const int rj = ridx / D2, rm2 = ridx - rj * D2;
+    const bool rlane = V == 16 ? (lane & 3) == 0 : (lane & 15) == 0;
 
-    for (int k = beg; k < end; ++k) {
-        const int e = eid[k];
-        const int d = nbr[k];
-        const float* gr = gb + (size_t)d * d_out;
-        float g[D3];
+    for (int k = beg; k < end; k += U) {
+        int e[U];
+        float g[U][D3], wv[U];
 #pragma unroll
-        for (int m3 = 0; m3 < D3; ++m3) g[m3] = cs * gr[m3];
-        const float wv = wb[(size_t)e * w_numel];
-        const float* Mk = Mb + (size_t)k * msz;
-        float gw = 0.f;
+        for (int j = 0; j < U; ++j) {
+            const int kk = k + j < end ? k + j : end - 1;  // past the end: re-read the last edge, contribute 0
+            e[j] = eid[kk];
+            const int d = nbr[kk];
+            const float* gr = gb + (size_t)d * d_out;
 #pragma unroll
-        for (int m1 = 0; m1 < D1; ++m1) {
-            float t = 0.f;
-#pragma unroll
-            for (int m3 = 0; m3 < D3; ++m3) t = fmaf(Mk[m1 * D3 + m3], g[m3], t);
-            gw = fmaf(xv[m1], t, gw);
-            gx[m1] = fmaf(wv, t, gx[m1]);
+            for (int m3 = 0; m3 < D3; ++m3) g[j][m3] = gr[m3];
+            wv[j] = wb[(size_t)e[j] * w_numel];
         }
-        if (active) dwb[(size_t)e * w_numel] = gw;
+        float q[NEED_DY ? V : 1];
         if (NEED_DY) {
-            float* dq = dyp + (size_t)e * py + p.py_off + chunk * D2;
 #pragma unroll
-            for (int m2 = 0; m2 < D2; ++m2) {
-                float q = 0.f;
+            for (int i = 0; i < V; ++i) q[i] = 0.f;
+        }
 #pragma unroll
-                for (int m3 = 0; m3 < D3; ++m3) q = fmaf(P[m2][m3], g[m3], q);
-                q = tfc_wave_sum(wv * q);  // idle lanes hold P = 0
-                if ((threadIdx.x & 63) == 0) dq[m2] = q;
+        for (int j = 0; j < U; ++j) {
+            const bool ok = k + j < end;
+            const int kk = ok ? k + j : end - 1;
+            const float* Mk = Mb + (size_t)kk * msz;
+            const float wj = ok ? wv[j] : 0.f;
+#pragma unroll
+            for (int m3 = 0; m3 < D3; ++m3) g[j][m3] *= cs;
+            float gw = 0.f;
+#pragma unroll
+            for (int m1 = 0; m1 < D1; ++m1) {
+                float t = 0.f;
+#pragma unroll
+                for (int m3 = 0; m3 < D3; ++m3) t = fmaf(Mk[m1 * D3 + m3], g[j][m3], t);
+                gw = fmaf(xv[m1], t, gw);
+                gx[m1] = fmaf(wj, t, gx[m1]);
             }
+            if (ok && active) dwb[(size_t)e[j] * w_numel] = gw;
+            if (NEED_DY) {
+#pragma unroll
+                for (int m2 = 0; m2 < D2; ++m2) {
+                    float s = 0.f;
+#pragma unroll
+                    for (int m3 = 0; m3 < D3; ++m3) s = fmaf(P[m2][m3], g[j][m3], s);
+                    q[j * D2 + m2] = wj * s;  // idle lanes hold P = 0
+                }
+            }
+        }
+        if (NEED_DY) {
+            float r;
+            if (V == 16) {
+                float (&q16)[16] = reinterpret_cast<float (&)[16]>(q);
+                r = tfc_wave_reduce16(q16);
+            } else {
+                float (&q4)[4] = reinterpret_cast<float (&)[4]>(q);
+                r = tfc_wave_reduce4(q4);
+            }
+            int es = e[0];
+#pragma unroll
+            for (int j = 1; j < U; ++j) es = rj == j ? e[j] : es;
+            if (rlane && rj < U && k + rj < end) dyp[(size_t)es * py + p.py_off + chunk * D2 + rm2] = r;
         }
     }
 }
 
-template <int L1, bool NEED_DY>
+template <int L1, bool NEED_DY, int LM>
 __device__ __forceinline__ void bwd_item(const float* __restrict__ x, const float* __restrict__ w,
                                          const float* __restrict__ gout, const float* __restrict__ M,
                                          const float* __restrict__ cgd, const int* __restrict__ eid,
@@ -276,8 +332,9 @@ __device__ __forceinline__ void bwd_item(const float* __restrict__ x, const floa
         const PathDev p = paths[grp_paths[it.grp_start + gi]];
 #define TFC_BWD_CASE(B, C)                                                                            \
     case (B)*4 + (C):                                                                                 \
-        bwd_path<L1, B, C, NEED_DY>(w, gout, M, cgd, eid, nbr, beg, end, p, u, uu, active, d_out,     \
-                                    w_numel, msz, py, scale, xv, gx, dw, dyp, it.chunk);              \
+        if constexpr ((B) <= LM && (C) <= LM)                                                         \
+            bwd_path<L1, B, C, NEED_DY>(w, gout, M, cgd, eid, nbr, beg, end, p, u, uu, active, d_out, \
+                                        w_numel, msz, py, scale, xv, gx, dw, dyp, it.chunk);          \
         break;
         switch (p.l2 * 4 + p.l3) {
             TFC_BWD_CASE(0, 0) TFC_BWD_CASE(0, 1) TFC_BWD_CASE(0, 2) TFC_BWD_CASE(0, 3)
@@ -295,7 +352,9 @@ __device__ __forceinline__ void bwd_item(const float* __restrict__ x, const floa
     }
 }
 
-template <bool NEED_DY>
+// LM: largest l any path of the plan uses.  The register allocation of the kernel is that of its
+// widest (l1, l2, l3) case, so plans without l = 3 get their own, leaner instantiation.
+template <bool NEED_DY, int LM>
 __global__ __launch_bounds__(256) void tfc_conv_bwd_kernel(
     const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ gout,
     const float* __restrict__ M, const float* __restrict__ cgd, const int* __restrict__ row_ptr,
@@ -315,19 +374,23 @@ __global__ __launch_bounds__(256) void tfc_conv_bwd_kernel(
     const int end = tfc_uniform(row_ptr[node + 1]);
     switch (it.l1) {
         case 0:
-            bwd_item<0, NEED_DY>(x, w, gout, M, cgd, eid, nbr, paths, grp_paths, it, beg, end, node, lane,
+            if constexpr (0 <= LM)
+                bwd_item<0, NEED_DY, LM>(x, w, gout, M, cgd, eid, nbr, paths, grp_paths, it, beg, end, node, lane,
                                  d_in, d_out, w_numel, msz, py, scale, dx, dw, dyp);
             break;
         case 1:
-            bwd_item<1, NEED_DY>(x, w, gout, M, cgd, eid, nbr, paths, grp_paths, it, beg, end, node, lane,
+            if constexpr (1 <= LM)
+                bwd_item<1, NEED_DY, LM>(x, w, gout, M, cgd, eid, nbr, paths, grp_paths, it, beg, end, node, lane,
                                  d_in, d_out, w_numel, msz, py, scale, dx, dw, dyp);
             break;
         case 2:
-            bwd_item<2, NEED_DY>(x, w, gout, M, cgd, eid, nbr, paths, grp_paths, it, beg, end, node, lane,
+            if constexpr (2 <= LM)
+                bwd_item<2, NEED_DY, LM>(x, w, gout, M, cgd, eid, nbr, paths, grp_paths, it, beg, end, node, lane,
                                  d_in, d_out, w_numel, msz, py, scale, dx, dw, dyp);
             break;
         case 3:
-            bwd_item<3, NEED_DY>(x, w, gout, M, cgd, eid, nbr, paths, grp_paths, it, beg, end, node, lane,
+            if constexpr (3 <= LM)
+                bwd_item<3, NEED_DY, LM>(x, w, gout, M, cgd, eid, nbr, paths, grp_paths, it, beg, end, node, lane,
                                  d_in, d_out, w_numel, msz, py, scale, dx, dw, dyp);
             break;
         default: break;
@@ -529,6 +592,8 @@ extern "C" int tfc_conv_plan_create(const tfc_path* paths, int32_t n_paths, int3
     pl->py = py;
     pl->n_fwd_items = (int)fwd_items.size();
     pl->n_bwd_items = (int)bwd_items.size();
+    pl->lmax = 0;
+    for (int i = 0; i < n_paths; ++i) pl->lmax = std::max(pl->lmax, std::max(pd[i].l1, std::max(pd[i].l2, pd[i].l3)));
     pl->paths = (PathDev*)(b + o_paths);
     pl->fwd_items = (FwdItem*)(b + o_fwd);
     pl->bwd_items = (BwdItem*)(b + o_bwd);
@@ -622,27 +687,25 @@ extern "C" int tfc_conv_bwd(const tfc_conv_plan* pl, const float* x, const float
     const long n_tasks = (long)n_nodes * pl->n_bwd_items;
     const long n_blocks = (n_tasks + 3) / 4;
     TFC_REQUIRE(n_blocks < (1LL << 31), TFC_EUNSUPPORTED, "tfc_conv_bwd: grid too large");
-    if (dy) {
-        {
-            TfcProfScope prof("tfc_conv_bwd_kernel", stream);
-            tfc_conv_bwd_kernel<true><<<(unsigned)n_blocks, 256, 0, stream>>>(
-                x, w, gout, M, pl->cgd, row_ptr, eid, nbr, pl->paths, pl->bwd_items, pl->grp_paths,
-                pl->n_bwd_items, n_tasks, pl->d_in, pl->d_out, pl->w_numel, pl->msz, pl->py, scale, dx, dw, dyp);
-        }
-        TFC_LAUNCH_CHECK("tfc_conv_bwd_kernel<dy>");
-        if (n_edges > 0) {
-            TfcProfScope prof("tfc_dy_reduce_kernel", stream);
-            tfc_dy_reduce_kernel<<<grid_for(n_edges * (long)pl->d_sh, 256, 2048), 256, 0, stream>>>(
-                dyp, pl->ylist_ptr, pl->ylist, (long)n_edges, pl->d_sh, pl->py, dy);
-            TFC_LAUNCH_CHECK("tfc_dy_reduce_kernel");
-        }
-    } else {
+#define TFC_BWD_LAUNCH(DY, LM)                                                                          \
+    tfc_conv_bwd_kernel<DY, LM><<<(unsigned)n_blocks, 256, 0, stream>>>(                                \
+        x, w, gout, M, pl->cgd, row_ptr, eid, nbr, pl->paths, pl->bwd_items, pl->grp_paths, pl->n_bwd_items, \
+        n_tasks, pl->d_in, pl->d_out, pl->w_numel, pl->msz, pl->py, scale, dx, dw, dy ? dyp : nullptr)
+    {
         TfcProfScope prof("tfc_conv_bwd_kernel", stream);
-        tfc_conv_bwd_kernel<false><<<(unsigned)n_blocks, 256, 0, stream>>>(
-            x, w, gout, M, pl->cgd, row_ptr, eid, nbr, pl->paths, pl->bwd_items, pl->grp_paths,
-            pl->n_bwd_items, n_tasks, pl->d_in, pl->d_out, pl->w_numel, pl->msz, pl->py, scale, dx, dw,
-            nullptr);
-        TFC_LAUNCH_CHECK("tfc_conv_bwd_kernel");
+        if (dy) {
+            if (pl->lmax <= 2) TFC_BWD_LAUNCH(true, 2); else TFC_BWD_LAUNCH(true, 3);
+        } else {
+            if (pl->lmax <= 2) TFC_BWD_LAUNCH(false, 2); else TFC_BWD_LAUNCH(false, 3);
+        }
+    }
+#undef TFC_BWD_LAUNCH
+    TFC_LAUNCH_CHECK("tfc_conv_bwd_kernel");
+    if (dy && n_edges > 0) {
+        TfcProfScope prof("tfc_dy_reduce_kernel", stream);
+        tfc_dy_reduce_kernel<<<grid_for(n_edges * (long)pl->d_sh, 256, 2048), 256, 0, stream>>>(
+            dyp, pl->ylist_ptr, pl->ylist, (long)n_edges, pl->d_sh, pl->py, dy);
+        TFC_LAUNCH_CHECK("tfc_dy_reduce_kernel");
     }
     return TFC_OK;
 }
