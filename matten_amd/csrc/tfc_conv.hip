@@ -61,6 +61,7 @@ struct tfc_conv_plan {
     int py;   // floats per edge of the partial-dy buffer
     int n_fwd_items, n_bwd_items;
     int lmax;  // largest l1, l2 or l3 of any path
+    long m_sig;  // hash of the layout of an M row (the list of (l1, l2, l3, y_off) blocks)
     int device;
     PathDev* paths;
     FwdItem* fwd_items;
@@ -592,6 +593,13 @@ extern "C" int tfc_conv_plan_create(const tfc_path* paths, int32_t n_paths, int3
     pl->py = py;
     pl->n_fwd_items = (int)fwd_items.size();
     pl->n_bwd_items = (int)bwd_items.size();
+    pl->m_sig = 1469598103934665603L;
+    for (auto& t : triples) {
+        int v[4];
+        std::tie(v[0], v[1], v[2], v[3]) = t;
+        for (int q = 0; q < 4; ++q) pl->m_sig = (pl->m_sig ^ (long)(v[q] + 1)) * 1099511628211L;
+    }
+    pl->m_sig &= 0x7fffffffffffffffL;
     pl->lmax = 0;
     for (int i = 0; i < n_paths; ++i) pl->lmax = std::max(pl->lmax, std::max(pd[i].l1, std::max(pd[i].l2, pd[i].l3)));
     pl->paths = (PathDev*)(b + o_paths);
@@ -628,9 +636,31 @@ static inline int grid_for(long n, int per_block, int cap = 8192) {
     return (int)g;
 }
 
-extern "C" int tfc_conv_fwd(const tfc_conv_plan* pl, const float* x, const float* y, const float* w,
-                            const int32_t* row_ptr, const int32_t* eid, const int32_t* nbr, int64_t n_nodes,
-                            int64_t n_edges, float scale, float* out, float* workspace, tfc_stream_t stream_) {
+extern "C" int64_t tfc_conv_m_signature(const tfc_conv_plan* plan) { return plan ? plan->m_sig : -1; }
+
+extern "C" int64_t tfc_conv_m_floats(const tfc_conv_plan* plan, int64_t n_edges) {
+    if (!plan || n_edges < 0) return -1;
+    const int64_t f = n_edges * (int64_t)plan->msz;
+    return f > 0 ? f : 1;
+}
+
+extern "C" int tfc_conv_m_build(const tfc_conv_plan* pl, const float* y, const int32_t* eid, int64_t n_edges,
+                                float* M, tfc_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    TFC_REQUIRE(pl, TFC_EINVAL, "tfc_conv_m_build: null plan");
+    TFC_REQUIRE(n_edges >= 0 && n_edges < (1LL << 31), TFC_EINVAL, "tfc_conv_m_build: bad edge count");
+    if (n_edges == 0) return TFC_OK;
+    TFC_REQUIRE(y && eid && M, TFC_EINVAL, "tfc_conv_m_build: null tensor");
+    TfcProfScope prof("tfc_m_prepass_kernel", stream);
+    tfc_m_prepass_kernel<<<grid_for(n_edges * (long)pl->msz, 256), 256, 0, stream>>>(
+        y, eid, pl->ments, pl->cgm, (long)n_edges, pl->msz, pl->d_sh, M);
+    TFC_LAUNCH_CHECK("tfc_m_prepass_kernel");
+    return TFC_OK;
+}
+
+extern "C" int tfc_conv_fwd_m(const tfc_conv_plan* pl, const float* x, const float* M, const float* w,
+                              const int32_t* row_ptr, const int32_t* eid, const int32_t* nbr, int64_t n_nodes,
+                              int64_t n_edges, float scale, float* out, tfc_stream_t stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     TFC_REQUIRE(pl, TFC_EINVAL, "tfc_conv_fwd: null plan");
     TFC_REQUIRE(n_nodes >= 0 && n_edges >= 0, TFC_EINVAL, "tfc_conv_fwd: negative size");
@@ -638,14 +668,7 @@ extern "C" int tfc_conv_fwd(const tfc_conv_plan* pl, const float* x, const float
                 "tfc_conv_fwd: more than 2^31 nodes or edges");
     if (n_nodes == 0) return TFC_OK;
     TFC_REQUIRE(x && out && row_ptr, TFC_EINVAL, "tfc_conv_fwd: null tensor");
-    TFC_REQUIRE(n_edges == 0 || (y && w && eid && nbr && workspace), TFC_EINVAL, "tfc_conv_fwd: null tensor");
-    float* M = workspace;
-    if (n_edges > 0) {
-        TfcProfScope prof("tfc_m_prepass_kernel", stream);
-        tfc_m_prepass_kernel<<<grid_for(n_edges * (long)pl->msz, 256), 256, 0, stream>>>(
-            y, eid, pl->ments, pl->cgm, (long)n_edges, pl->msz, pl->d_sh, M);
-        TFC_LAUNCH_CHECK("tfc_m_prepass_kernel");
-    }
+    TFC_REQUIRE(n_edges == 0 || (M && w && eid && nbr), TFC_EINVAL, "tfc_conv_fwd: null tensor");
     const long n_tasks = (long)n_nodes * pl->n_fwd_items;
     const long n_blocks = (n_tasks + 3) / 4;
     TFC_REQUIRE(n_blocks < (1LL << 31), TFC_EUNSUPPORTED, "tfc_conv_fwd: grid too large");
@@ -659,10 +682,28 @@ extern "C" int tfc_conv_fwd(const tfc_conv_plan* pl, const float* x, const float
     return TFC_OK;
 }
 
-extern "C" int tfc_conv_bwd(const tfc_conv_plan* pl, const float* x, const float* y, const float* w,
-                            const float* gout, const int32_t* row_ptr, const int32_t* eid, const int32_t* nbr,
-                            int64_t n_nodes, int64_t n_edges, float scale, float* dx, float* dw, float* dy,
-                            float* workspace, tfc_stream_t stream_) {
+extern "C" int tfc_conv_fwd(const tfc_conv_plan* pl, const float* x, const float* y, const float* w,
+                            const int32_t* row_ptr, const int32_t* eid, const int32_t* nbr, int64_t n_nodes,
+                            int64_t n_edges, float scale, float* out, float* workspace, tfc_stream_t stream) {
+    TFC_REQUIRE(pl, TFC_EINVAL, "tfc_conv_fwd: null plan");
+    TFC_REQUIRE(n_edges <= 0 || n_nodes <= 0 || (y && eid && workspace), TFC_EINVAL, "tfc_conv_fwd: null tensor");
+    if (n_nodes > 0 && n_edges > 0) {
+        const int rc = tfc_conv_m_build(pl, y, eid, n_edges, workspace, stream);
+        if (rc) return rc;
+    }
+    return tfc_conv_fwd_m(pl, x, workspace, w, row_ptr, eid, nbr, n_nodes, n_edges, scale, out, stream);
+}
+
+extern "C" int64_t tfc_conv_dy_floats(const tfc_conv_plan* plan, int64_t n_edges) {
+    if (!plan || n_edges < 0) return -1;
+    const int64_t f = n_edges * (int64_t)plan->py;
+    return f > 0 ? f : 1;
+}
+
+extern "C" int tfc_conv_bwd_m(const tfc_conv_plan* pl, const float* x, const float* M, const float* w,
+                              const float* gout, const int32_t* row_ptr, const int32_t* eid, const int32_t* nbr,
+                              int64_t n_nodes, int64_t n_edges, float scale, float* dx, float* dw, float* dy,
+                              float* dyp, tfc_stream_t stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     TFC_REQUIRE(pl, TFC_EINVAL, "tfc_conv_bwd: null plan");
     TFC_REQUIRE(n_nodes >= 0 && n_edges >= 0, TFC_EINVAL, "tfc_conv_bwd: negative size");
@@ -670,20 +711,12 @@ extern "C" int tfc_conv_bwd(const tfc_conv_plan* pl, const float* x, const float
                 "tfc_conv_bwd: more than 2^31 nodes or edges");
     if (n_nodes == 0) return TFC_OK;
     TFC_REQUIRE(x && gout && dx && row_ptr, TFC_EINVAL, "tfc_conv_bwd: null tensor");
-    TFC_REQUIRE(n_edges == 0 || (y && w && dw && eid && nbr && workspace), TFC_EINVAL,
+    TFC_REQUIRE(n_edges == 0 || (M && w && dw && eid && nbr && (!dy || dyp)), TFC_EINVAL,
                 "tfc_conv_bwd: null tensor");
-    float* M = workspace;
-    float* dyp = workspace + (size_t)n_edges * pl->msz;
     // columns of dx / dw that no path touches must still be defined
     tfc_fill_kernel<<<grid_for((long)n_nodes * pl->d_in, 256, 2048), 256, 0, stream>>>(
         dx, (long)n_nodes * pl->d_in, 0.f);
     TFC_LAUNCH_CHECK("tfc_fill_kernel");
-    if (n_edges > 0) {
-        TfcProfScope prof("tfc_m_prepass_kernel", stream);
-        tfc_m_prepass_kernel<<<grid_for(n_edges * (long)pl->msz, 256), 256, 0, stream>>>(
-            y, eid, pl->ments, pl->cgm, (long)n_edges, pl->msz, pl->d_sh, M);
-        TFC_LAUNCH_CHECK("tfc_m_prepass_kernel");
-    }
     const long n_tasks = (long)n_nodes * pl->n_bwd_items;
     const long n_blocks = (n_tasks + 3) / 4;
     TFC_REQUIRE(n_blocks < (1LL << 31), TFC_EUNSUPPORTED, "tfc_conv_bwd: grid too large");
@@ -708,4 +741,19 @@ extern "C" int tfc_conv_bwd(const tfc_conv_plan* pl, const float* x, const float
         TFC_LAUNCH_CHECK("tfc_dy_reduce_kernel");
     }
     return TFC_OK;
+}
+
+extern "C" int tfc_conv_bwd(const tfc_conv_plan* pl, const float* x, const float* y, const float* w,
+                            const float* gout, const int32_t* row_ptr, const int32_t* eid, const int32_t* nbr,
+                            int64_t n_nodes, int64_t n_edges, float scale, float* dx, float* dw, float* dy,
+                            float* workspace, tfc_stream_t stream) {
+    TFC_REQUIRE(pl, TFC_EINVAL, "tfc_conv_bwd: null plan");
+    TFC_REQUIRE(n_edges <= 0 || n_nodes <= 0 || (y && eid && workspace), TFC_EINVAL, "tfc_conv_bwd: null tensor");
+    if (n_nodes > 0 && n_edges > 0) {
+        const int rc = tfc_conv_m_build(pl, y, eid, n_edges, workspace, stream);
+        if (rc) return rc;
+    }
+    float* dyp = workspace ? workspace + (size_t)(n_edges > 0 ? n_edges : 0) * pl->msz : nullptr;
+    return tfc_conv_bwd_m(pl, x, workspace, w, gout, row_ptr, eid, nbr, n_nodes, n_edges, scale, dx, dw, dy, dyp,
+                          stream);
 }

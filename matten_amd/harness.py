@@ -55,7 +55,10 @@ class ConvStack(torch.nn.Module):
 
     def forward(self, batch, n_graphs: int):
         data = dict(batch)
-        x = self.embedding(data["species_index"])
+        # embedding lookup as one-hot @ table: same values, and a backward that is one small GEMM
+        # instead of torch's single-block embedding_backward kernel
+        w = self.embedding.weight
+        x = torch.nn.functional.one_hot(data["species_index"], w.shape[0]).to(w.dtype) @ w
         data[K.NODE_FEATURES] = x
         data[K.NODE_ATTRS] = x
         data = self.spharm_edges(data)

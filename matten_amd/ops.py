@@ -96,6 +96,25 @@ class EdgeOrdering:
         self.by_dst = build(1, 0, 0)  # centre = receiver, nbr = sender
         self.by_src = build(0, 1, 1)  # centre = sender,   nbr = receiver
         self._edge_rows = None
+        self._m_cache = {}
+
+    def m_matrices(self, plan: "ConvPlan", y: torch.Tensor, rows) -> torch.Tensor:
+        """The per-edge matrices M_e (CG tensor contracted with the edge attributes) in the order of
+        `rows`, built once and shared by every layer whose plan lays M out the same way (and that
+        sees the same edge-attribute tensor): tfc_conv_m_build."""
+        L = _lib.lib()
+        h = plan.handle(y.device)
+        key = (int(L.tfc_conv_m_signature(h)), rows[1].data_ptr(), y.data_ptr(), y._version)
+        hit = self._m_cache.get(key)
+        if hit is not None:
+            return hit[0]
+        E = y.shape[0]
+        M = torch.empty(int(L.tfc_conv_m_floats(h, E)), dtype=torch.float32, device=y.device)
+        _lib.check(L.tfc_conv_m_build(h, _ptr(y), _ptr(rows[1]), E, _ptr(M), _stream()))
+        if len(self._m_cache) >= 4:
+            self._m_cache.pop(next(iter(self._m_cache)))
+        self._m_cache[key] = (M, y)  # holding y keeps its address from being reused while cached
+        return M
 
     def per_edge(self):
         """Ordering in which every edge is its own centre (used to materialise per-edge
@@ -183,7 +202,7 @@ class ConvPlan:
 
 class _ConvFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, y, w, plan: ConvPlan, fwd_rows, bwd_rows, n_out: int, scale: float):
+    def forward(ctx, x, y, w, plan: ConvPlan, ordering, fwd_rows, bwd_rows, n_out: int, scale: float):
         x, y, w = _f32(x, "x"), _f32(y, "edge_attrs"), _f32(w, "weights")
         E = y.shape[0]
         if x.shape[1] != plan.d_in or y.shape[1] != plan.d_sh or w.shape[1] != plan.w_numel or w.shape[0] != E:
@@ -195,15 +214,15 @@ class _ConvFn(torch.autograd.Function):
         if rp.numel() != n_out + 1:
             raise ValueError("conv: ordering does not match the number of output rows")
         out = torch.empty(n_out, plan.d_out, dtype=torch.float32, device=x.device)
-        ws = plan.workspace(x.device, E, False)
+        M = ordering.m_matrices(plan, y, fwd_rows)
         _lib.check(
-            _lib.lib().tfc_conv_fwd(
-                plan.handle(x.device), _ptr(x), _ptr(y), _ptr(w), _ptr(rp), _ptr(eid), _ptr(nbr), n_out, E,
-                float(scale), _ptr(out), _ptr(ws), _stream(),
+            _lib.lib().tfc_conv_fwd_m(
+                plan.handle(x.device), _ptr(x), _ptr(M), _ptr(w), _ptr(rp), _ptr(eid), _ptr(nbr), n_out, E,
+                float(scale), _ptr(out), _stream(),
             )
         )
         ctx.save_for_backward(x, y, w)
-        ctx.plan, ctx.bwd_rows, ctx.scale = plan, bwd_rows, float(scale)
+        ctx.plan, ctx.bwd_rows, ctx.scale, ctx.ordering = plan, bwd_rows, float(scale), ordering
         return out
 
     @staticmethod
@@ -217,14 +236,17 @@ class _ConvFn(torch.autograd.Function):
         dx = torch.empty_like(x)
         dw = torch.empty_like(w)
         dy = torch.empty_like(y) if need_dy else None
-        ws = plan.workspace(x.device, E, need_dy)
+        L = _lib.lib()
+        h = plan.handle(x.device)
+        M = ctx.ordering.m_matrices(plan, y, ctx.bwd_rows)
+        dyp = torch.empty(int(L.tfc_conv_dy_floats(h, E)), dtype=torch.float32, device=x.device) if need_dy else None
         _lib.check(
-            _lib.lib().tfc_conv_bwd(
-                plan.handle(x.device), _ptr(x), _ptr(y), _ptr(w), _ptr(gout), _ptr(rp), _ptr(eid), _ptr(nbr),
-                x.shape[0], E, ctx.scale, _ptr(dx), _ptr(dw), _ptr(dy), _ptr(ws), _stream(),
+            L.tfc_conv_bwd_m(
+                h, _ptr(x), _ptr(M), _ptr(w), _ptr(gout), _ptr(rp), _ptr(eid), _ptr(nbr),
+                x.shape[0], E, ctx.scale, _ptr(dx), _ptr(dw), _ptr(dy), _ptr(dyp), _stream(),
             )
         )
-        return dx, dy, dw, None, None, None, None, None
+        return dx, dy, dw, None, None, None, None, None, None
 
 
 def conv(x, y, w, plan: ConvPlan, ordering: EdgeOrdering, scale: float = 1.0, per_edge: bool = False):
@@ -232,8 +254,8 @@ def conv(x, y, w, plan: ConvPlan, ordering: EdgeOrdering, scale: float = 1.0, pe
     returns the un-summed messages [E, d_out] instead (each edge is its own row)."""
     if per_edge:
         rps, eids, _ = ordering.by_src  # backward gathers the gradient row of the edge itself
-        return _ConvFn.apply(x, y, w, plan, ordering.per_edge(), (rps, eids, eids), ordering.n_edges, scale)
-    return _ConvFn.apply(x, y, w, plan, ordering.by_dst, ordering.by_src, ordering.n_nodes, scale)
+        return _ConvFn.apply(x, y, w, plan, ordering, ordering.per_edge(), (rps, eids, eids), ordering.n_edges, scale)
+    return _ConvFn.apply(x, y, w, plan, ordering, ordering.by_dst, ordering.by_src, ordering.n_nodes, scale)
 
 
 class _ScatterAddFn(torch.autograd.Function):
