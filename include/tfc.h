@@ -252,6 +252,20 @@ int tfc_gemm_group(const tfc_gemm_desc* descs, int32_t n_descs, tfc_stream_t str
  * Split sums are deterministic: partial tiles are stored and added in a fixed order. */
 int64_t tfc_gemm_workspace_floats(int64_t m, int64_t n, int64_t k);
 
+/* Channel-contiguous copy of feature rows, for the operands of the dense contractions above:
+ * e3nn stores a block as [mul][2l+1] (eigenn feature layout, see the conventions at the top), which
+ * gives the contraction index u of o3.Linear / FullyConnectedTensorProduct the stride 2l+1; block b
+ * of `out` is [dim_b][n_rows][mul_b] with u fastest:
+ *     out[off_b * n_rows + (m * n_rows + n) * mul_b + u] = x[n * d_row + off_b + u * dim_b + m]
+ * Columns of x outside every block are not copied. */
+typedef struct tfc_ir_block {
+    int32_t off; /* first column of the block in a row of x */
+    int32_t mul; /* channels */
+    int32_t dim; /* 2l+1 */
+} tfc_ir_block;
+int tfc_ir_transpose(const float* x, int64_t n_rows, int32_t d_row, const tfc_ir_block* blocks,
+                     int32_t n_blocks, float* out, tfc_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------
  * Gate non-linearity (e3nn.nn.Gate built at eigenn/nn/utils.py:134-140, applied at
  * eigenn/nn/point_conv.py:339).  The input row is [scalars | gates | gated]; the output row is

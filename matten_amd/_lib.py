@@ -64,6 +64,10 @@ class GemmDesc(C.Structure):
     ]
 
 
+class IrBlock(C.Structure):
+    _fields_ = [("off", C.c_int32), ("mul", C.c_int32), ("dim", C.c_int32)]
+
+
 class GateSeg(C.Structure):
     _fields_ = [
         ("in_off", C.c_int32),
@@ -111,6 +115,7 @@ SIGNATURES = {
     "tfc_gemm": (C.c_int, [C.POINTER(GemmDesc), _P]),
     "tfc_gemm_group": (C.c_int, [C.POINTER(GemmDesc), _I32, _P]),
     "tfc_gemm_workspace_floats": (_I64, [_I64, _I64, _I64]),
+    "tfc_ir_transpose": (C.c_int, [_P, _I64, _I32, C.POINTER(IrBlock), _I32, _P, _P]),
     "tfc_gate_fwd": (C.c_int, [C.POINTER(GateSeg), _I32, _P, _I64, _I32, _I32, _P, _P]),
     "tfc_profile_enable": (C.c_int, [C.c_int]),
     "tfc_profile_reset": (C.c_int, []),

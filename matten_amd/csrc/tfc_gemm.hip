@@ -51,7 +51,6 @@ struct Problem {
     int splits;       // > 1: K is cut into `splits` ranges
     int block_begin;  // first virtual block of this problem in the launch
     int accumulate, epilogue;
-    int a1_bc, a2_bc;  // 16-byte staging only: the factor is constant over a group of 4
     float alpha, act_cst;
 };
 
@@ -98,8 +97,7 @@ struct Operand {
 
     __device__ __forceinline__ void load(const float* __restrict__ p, const float* __restrict__ p2,
                                          const long* __restrict__ roff, const long* __restrict__ roff2,
-                                         const long* __restrict__ ko, const long* __restrict__ ko2, int t, bool,
-                                         bool) {
+                                         const long* __restrict__ ko, const long* __restrict__ ko2, int t) {
         if (KFAST) {
             const int kk = t % BK;
             const long o = ko[kk];
@@ -143,27 +141,22 @@ struct Operand {
 };
 
 // 16-byte variant: every thread moves groups of 4 elements that are consecutive along the walked
-// index.  Each factor is either contiguous there (one global_load_dwordx4) or constant over the
-// group (`bc`: one dword, replicated).  The host selects this variant only when the maps, the
-// base pointers and the extents guarantee aligned, in-bounds groups (vec_ok()).
+// index.  A single factor must be contiguous there (one global_load_dwordx4 per group).  With two
+// factors, the FIRST is constant over a group (one dword, e.g. x[n,u,m] over the attribute index
+// v of the self connection) and the SECOND contiguous; the host swaps the factors into that order
+// and selects this variant only when the maps, the base pointers and the extents guarantee
+// aligned, in-bounds groups (flags_of()).
 template <int BX, bool KFAST, bool HAS2>
 struct Operand<BX, KFAST, HAS2, true> {
     static constexpr int NV = BX * BK / 1024;  // groups per thread
     static constexpr int S = BX + 4;
-    float4 v[NV], v2[HAS2 ? NV : 1];
-
-    static __device__ __forceinline__ float4 fetch(const float* __restrict__ p, bool bc) {
-        if (bc) {
-            const float s = *p;
-            return make_float4(s, s, s, s);
-        }
-        return *reinterpret_cast<const float4*>(p);
-    }
+    float4 v[NV];
+    float s[HAS2 ? NV : 1];
 
     __device__ __forceinline__ void load(const float* __restrict__ p, const float* __restrict__ p2,
                                          const long* __restrict__ roff, const long* __restrict__ roff2,
-                                         const long* __restrict__ ko, const long* __restrict__ ko2, int t, bool bc1,
-                                         bool bc2) {
+                                         const long* __restrict__ ko, const long* __restrict__ ko2, int t) {
+        // (p, roff, ko) address the broadcast factor when HAS2, the only factor otherwise
         if (KFAST) {
             const int kq = t & 3;  // k = 4 kq .. 4 kq + 3
             const long o = ko[4 * kq];
@@ -171,8 +164,12 @@ struct Operand<BX, KFAST, HAS2, true> {
 #pragma unroll
             for (int q = 0; q < NV; ++q) {
                 const int x = (t >> 2) + 64 * q;
-                v[q] = fetch(p + roff[x] + o, bc1);
-                if (HAS2) v2[q] = fetch(p2 + roff2[x] + o2, bc2);
+                if (HAS2) {
+                    s[q] = p[roff[x] + o];
+                    v[q] = *reinterpret_cast<const float4*>(p2 + roff2[x] + o2);
+                } else {
+                    v[q] = *reinterpret_cast<const float4*>(p + roff[x] + o);
+                }
             }
         } else {
             const int xq = t % (BX / 4);  // x = 4 xq .. 4 xq + 3
@@ -181,8 +178,12 @@ struct Operand<BX, KFAST, HAS2, true> {
 #pragma unroll
             for (int q = 0; q < NV; ++q) {
                 const int kk = t / (BX / 4) + (1024 / BX) * q;
-                v[q] = fetch(p + r + ko[kk], bc1);
-                if (HAS2) v2[q] = fetch(p2 + r2 + ko2[kk], bc2);
+                if (HAS2) {
+                    s[q] = p[r + ko[kk]];
+                    v[q] = *reinterpret_cast<const float4*>(p2 + r2 + ko2[kk]);
+                } else {
+                    v[q] = *reinterpret_cast<const float4*>(p + r + ko[kk]);
+                }
             }
         }
     }
@@ -192,17 +193,23 @@ struct Operand<BX, KFAST, HAS2, true> {
         for (int q = 0; q < NV; ++q) {
             float4 a = v[q];
             if (HAS2) {
-                a.x *= v2[q].x;
-                a.y *= v2[q].y;
-                a.z *= v2[q].z;
-                a.w *= v2[q].w;
+                a.x *= s[q];
+                a.y *= s[q];
+                a.z *= s[q];
+                a.w *= s[q];
             }
             if (KFAST) {
                 const int k = 4 * (t & 3), x = (t >> 2) + 64 * q;
-                lds[(k + 0) * S + x] = k + 0 < k_left ? a.x : 0.f;
-                lds[(k + 1) * S + x] = k + 1 < k_left ? a.y : 0.f;
-                lds[(k + 2) * S + x] = k + 2 < k_left ? a.z : 0.f;
-                lds[(k + 3) * S + x] = k + 3 < k_left ? a.w : 0.f;
+                if (k_left < BK) {  // K tail (last tile only)
+                    a.x = k + 0 < k_left ? a.x : 0.f;
+                    a.y = k + 1 < k_left ? a.y : 0.f;
+                    a.z = k + 2 < k_left ? a.z : 0.f;
+                    a.w = k + 3 < k_left ? a.w : 0.f;
+                }
+                lds[(k + 0) * S + x] = a.x;
+                lds[(k + 1) * S + x] = a.y;
+                lds[(k + 2) * S + x] = a.z;
+                lds[(k + 3) * S + x] = a.w;
             } else {
                 const int k = t / (BX / 4) + (1024 / BX) * q, x = 4 * (t % (BX / 4));
                 if (k >= k_left) a = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -238,7 +245,6 @@ __global__ __launch_bounds__(256, (TM * TN == 4 ? 4 : 1)) void tfc_gemm_kernel(c
     const float* __restrict__ pb = P.b;
     const int K = P.k;
     const Map ka1 = P.a1_k, ka2 = P.a2_k, kb = P.b_k;
-    const bool bc1 = P.a1_bc != 0, bc2 = P.a2_bc != 0;
 
     const int local = vb - P.block_begin;
     const int nbm = (P.m + BM - 1) / BM, nbn = (P.n + BN - 1) / BN;
@@ -295,22 +301,15 @@ __global__ __launch_bounds__(256, (TM * TN == 4 ? 4 : 1)) void tfc_gemm_kernel(c
     Operand<BM, A_KFAST, HAS2, AV> A;
     Operand<BN, B_KFAST, false, BV> B;
     if (n_tiles > 0) {
-        A.load(pa1, pa2, roffA, roffA2, koff[0][0], koff[0][1], t, bc1, bc2);
-        B.load(pb, nullptr, roffB, nullptr, koff[0][2], nullptr, t, false, false);
+        A.load(pa1, pa2, roffA, roffA2, koff[0][0], koff[0][1], t);
+        B.load(pb, nullptr, roffB, nullptr, koff[0][2], nullptr, t);
         A.store(tiles, t, K - kt_begin * BK);
         B.store(tiles + BK * SA, t, K - kt_begin * BK);
     }
     __syncthreads();
 
     const int half = lane >> 5, l31 = lane & 31;
-    for (int i = 0; i < n_tiles; ++i) {
-        const int cur = i & 1, nxt = cur ^ 1;
-        const bool more = i + 1 < n_tiles;
-        if (more) {
-            const int kb_ = ((i + 1) / KT) & 1, ko_ = ((i + 1) % KT) * BK;
-            A.load(pa1, pa2, roffA, roffA2, koff[kb_][0] + ko_, koff[kb_][1] + ko_, t, bc1, bc2);
-            B.load(pb, nullptr, roffB, nullptr, koff[kb_][2] + ko_, nullptr, t, false, false);
-        }
+    auto mfma_tile = [&](int cur) {
         const float* As = tiles + cur * TILE;
         const float* Bs = As + BK * SA;
 #pragma unroll
@@ -326,16 +325,28 @@ __global__ __launch_bounds__(256, (TM * TN == 4 ? 4 : 1)) void tfc_gemm_kernel(c
                 for (int j = 0; j < TN; ++j)
                     acc[ii][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[ii], bf[j], acc[ii][j], 0, 0, 0);
         }
+    };
+    // steady state: tile i + 1 is loaded and staged unconditionally (the last tile is peeled off, so
+    // that the staging registers are not live under a condition across the MFMA block)
+    for (int i = 0; i + 1 < n_tiles; ++i) {
+        const int cur = i & 1, nxt = cur ^ 1;
+        {
+            const int kb_ = ((i + 1) / KT) & 1, ko_ = ((i + 1) % KT) * BK;
+            A.load(pa1, pa2, roffA, roffA2, koff[kb_][0] + ko_, koff[kb_][1] + ko_, t);
+            B.load(pb, nullptr, roffB, nullptr, koff[kb_][2] + ko_, nullptr, t);
+        }
+        mfma_tile(cur);
         // the offsets of tiles i + KT .. replace those of tiles i - KT .. i - 1 (last read before
         // the previous barrier); they are first read in iteration i + KT - 1
         if (i % KT == 0 && i + KT < n_tiles) fill_koff(i + KT);
-        if (more) {
+        {
             const int k_left = K - (kt_begin + i + 1) * BK;
             A.store(tiles + nxt * TILE, t, k_left);
             B.store(tiles + nxt * TILE + BK * SA, t, k_left);
         }
         __syncthreads();
     }
+    if (n_tiles > 0) mfma_tile((n_tiles - 1) & 1);
 
     // epilogue: acc[i][j][reg] is C[row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)][col = lane&31]
 #pragma unroll
@@ -467,29 +478,33 @@ struct Flags {
 // gathers, so the 128-byte lines a wave's load instruction touches (one per cycle), not the
 // matrix pipe, set the speed when the 64 addresses are spread out; 16-byte loads need a quarter
 // of the instructions.
-Flags flags_of(const tfc_gemm_desc& d, int* a1_bc, int* a2_bc) {
+// *swap12: the 16-byte path wants the broadcast factor first; set when a1 and a2 must trade places
+Flags flags_of(const tfc_gemm_desc& d, bool* swap12) {
     Flags f;
     f.has2 = d.a2 != nullptr;
     int cost[2];
-    bool vec[2];
-    int bc1[2] = {0, 0}, bc2[2] = {0, 0};
+    bool vec[2], swp[2] = {false, false};
     for (int kf = 0; kf < 2; ++kf) {
         const tfc_imap& fast1 = kf ? d.a1_k : d.a1_r;
         const tfc_imap& slow1 = kf ? d.a1_r : d.a1_k;
         const long nf = kf ? d.k : d.m, ns = kf ? d.m : d.k;
         int lines = lines_touched(d.a1_r, d.a1_k, d.m, d.k, kf);
-        bool ok = nf >= 4 && nf % 4 == 0 && factor_vec_ok(d.a1, fast1, nf, slow1, ns, &bc1[kf]);
+        int bc1 = 0, bc2 = 0;
+        bool ok = nf >= 4 && nf % 4 == 0 && factor_vec_ok(d.a1, fast1, nf, slow1, ns, &bc1);
         if (f.has2) {
             lines += lines_touched(d.a2_r, d.a2_k, d.m, d.k, kf);
-            ok = ok && factor_vec_ok(d.a2, kf ? d.a2_k : d.a2_r, nf, kf ? d.a2_r : d.a2_k, ns, &bc2[kf]);
+            ok = ok && factor_vec_ok(d.a2, kf ? d.a2_k : d.a2_r, nf, kf ? d.a2_r : d.a2_k, ns, &bc2);
+            ok = ok && (bc1 != bc2);  // one broadcast, one contiguous
+            swp[kf] = ok && bc2;
+        } else {
+            ok = ok && !bc1;
         }
         vec[kf] = ok;
         cost[kf] = lines * (ok ? 1 : 3);
     }
     f.a_kfast = cost[1] <= cost[0];
     f.av = vec[f.a_kfast];
-    *a1_bc = bc1[f.a_kfast];
-    *a2_bc = f.has2 ? bc2[f.a_kfast] : 0;
+    *swap12 = swp[f.a_kfast];
     for (int kf = 0; kf < 2; ++kf) {
         const long nf = kf ? d.k : d.n, ns = kf ? d.n : d.k;
         int bc = 0;
@@ -532,7 +547,6 @@ int convert(const tfc_gemm_desc* d, Problem* p) {
     p->act_cst = d->act_cst;
     p->accumulate = d->accumulate;
     p->epilogue = d->epilogue;
-    p->a1_bc = p->a2_bc = 0;
     int rc;
     if ((rc = convert_map(d->a1_r, &p->a1_r, "a1_r"))) return rc;
     if ((rc = convert_map(d->a1_k, &p->a1_k, "a1_k"))) return rc;
@@ -668,19 +682,22 @@ extern "C" int tfc_gemm_group(const tfc_gemm_desc* descs, int32_t n_descs, tfc_s
             done[first] = 1;
             continue;
         }
-        int bc1 = 0, bc2 = 0;
-        const Flags f = flags_of(descs[first], &bc1, &bc2);
+        bool swap12 = false;
+        const Flags f = flags_of(descs[first], &swap12);
         Group g;
         g.n = 0;
         float* ws = nullptr;
         long ws_floats = 0;
         const char* tag = descs[first].tag ? descs[first].tag : "tfc_gemm_kernel";
         for (int i = first; i < n_descs && g.n < MAXP; ++i) {
-            if (done[i] || descs[i].m == 0 || descs[i].n == 0 || !(flags_of(descs[i], &bc1, &bc2) == f)) continue;
+            if (done[i] || descs[i].m == 0 || descs[i].n == 0 || !(flags_of(descs[i], &swap12) == f)) continue;
             const int rc = convert(&descs[i], &g.p[g.n]);
             if (rc) return rc;
-            g.p[g.n].a1_bc = bc1;
-            g.p[g.n].a2_bc = bc2;
+            if (swap12) {
+                std::swap(g.p[g.n].a1, g.p[g.n].a2);
+                std::swap(g.p[g.n].a1_r, g.p[g.n].a2_r);
+                std::swap(g.p[g.n].a1_k, g.p[g.n].a2_k);
+            }
             if (descs[i].workspace && descs[i].workspace_floats > ws_floats) {
                 ws = descs[i].workspace;
                 ws_floats = descs[i].workspace_floats;

@@ -17,7 +17,7 @@ from typing import List, Optional, Sequence, Tuple
 import torch
 
 from . import _lib
-from ._lib import GateSeg, GemmDesc, IMap, Path
+from ._lib import GateSeg, GemmDesc, IMap, IrBlock, Path
 
 __all__ = [
     "EdgeOrdering",
@@ -532,6 +532,19 @@ def _gemm_waves(items):
         _gemm_group(group)
 
 
+def _ir_transpose(t: torch.Tensor, blocks) -> torch.Tensor:
+    """Channel-contiguous copy of the (off, mul, dim) blocks of the rows of `t` (tfc_ir_transpose):
+    block b of the flat result starts at off_b * N and is laid out [dim_b][N][mul_b]."""
+    n, d_row = t.shape
+    blocks = sorted(set(blocks))
+    arr = (IrBlock * len(blocks))()
+    for a, (off, mul, dim) in zip(arr, blocks):
+        a.off, a.mul, a.dim = off, mul, dim
+    out = torch.empty(max(n * d_row, 1), dtype=torch.float32, device=t.device)
+    _lib.check(_lib.lib().tfc_ir_transpose(_ptr(t), n, d_row, arr, len(blocks), _ptr(out), _stream()))
+    return out
+
+
 def _p(t: torch.Tensor, off: int = 0):
     return t.data_ptr() + 4 * int(off)
 
@@ -732,6 +745,9 @@ class _FctpFn(torch.autograd.Function):
         g = _f32(g, "grad_output")
         n = x.shape[0]
         dx = da = dw = None
+        # channel-contiguous copies ([dim][N][mul] per block): the contractions below all run over
+        # channels, which e3nn's [mul][dim] blocks hold at stride dim
+        gt = _ir_transpose(g, [(oo, mw, d) for _, _, _, _, oo, mw, d, _, _ in spec.instructions])
         if ctx.needs_input_grad[0]:
             dx = (torch.empty if spec.x_covered else torch.zeros)(n, spec.d_x, dtype=torch.float32, device=x.device)
 
@@ -740,26 +756,27 @@ class _FctpFn(torch.autograd.Function):
                 return lambda acc: _desc(
                     n * d, mu, mv * mw, _p(a, ao), _p(weight, wo), _p(dx, xo),
                     a1_r=_imap(1, d, spec.d_a, 0, 0), a1_k=_imap(1, mw, 1, 0, 0),
-                    a2=_p(g, oo), a2_r=_imap(1, d, spec.d_out, 0, 1), a2_k=_imap(1, mw, 0, 0, d),
+                    a2=_p(gt, oo * n), a2_r=_imap(1, d, mw, 0, n * mw), a2_k=_imap(1, mw, 0, 0, 1),
                     b_k=_lin(1), b_j=_lin(mv * mw), c_r=_imap(1, d, spec.d_x, 0, 1), c_j=_lin(d), alpha=alpha,
                     accumulate=acc, tag=b"gemm_fctp_dx",
                 )
 
             _gemm_waves([(ins[0], bdx(*ins)) for ins in spec.instructions])
         if ctx.needs_input_grad[1]:
-            # da[n, v] = sum_{(u,w,k)} x[n,u,k] g[n,w,k] W[u,v,w].  Every instruction adds to the same
+            # da[n, v] = sum_{(k,u,w)} x[n,u,k] g[n,w,k] W[u,v,w].  Every instruction adds to the same
             # block of `da`: each writes its own partial [N, mul_v] in one grouped launch, and the
             # partials are then summed in instruction order (deterministic).
+            xt = _ir_transpose(x, [(xo, mu, d) for xo, mu, _, _, _, _, d, _, _ in spec.instructions])
             ni = len(spec.instructions)
             part = torch.empty(ni, n, spec.d_a, dtype=torch.float32, device=x.device)
             if not spec.a_covered or any(ins[3] != spec.d_a for ins in spec.instructions):
                 part.zero_()
             _gemm_group([
                 _desc(
-                    n, mv, mu * mw * d, _p(x, xo), _p(weight, wo), _p(part, i * n * spec.d_a + ao),
-                    a1_r=_lin(spec.d_x), a1_k=_imap(mw, d, d, 0, 1),
-                    a2=_p(g, oo), a2_r=_lin(spec.d_out), a2_k=_imap(mw, d, 0, d, 1),
-                    b_k=_imap(mw, d, mv * mw, 1, 0), b_j=_lin(mw), c_r=_lin(spec.d_a), c_j=_lin(1), alpha=alpha,
+                    n, mv, d * mu * mw, _p(xt, xo * n), _p(weight, wo), _p(part, i * n * spec.d_a + ao),
+                    a1_r=_lin(mu), a1_k=_imap(mu, mw, n * mu, 1, 0),
+                    a2=_p(gt, oo * n), a2_r=_lin(mw), a2_k=_imap(mu, mw, n * mw, 0, 1),
+                    b_k=_imap(mu, mw, 0, mv * mw, 1), b_j=_lin(mw), c_r=_lin(spec.d_a), c_j=_lin(1), alpha=alpha,
                     tag=b"gemm_fctp_da",
                 )
                 for i, (xo, mu, ao, mv, oo, mw, d, wo, alpha) in enumerate(spec.instructions)
@@ -770,10 +787,10 @@ class _FctpFn(torch.autograd.Function):
             # dW[(u,v), w] = sum_{(n,k)} x[n,u,k] a[n,v] g[n,w,k]
             _gemm_group([
                 _desc(
-                    mu * mv, mw, n * d, _p(x, xo), _p(g, oo), _p(dw, wo),
+                    mu * mv, mw, n * d, _p(x, xo), _p(gt, oo * n), _p(dw, wo),
                     a1_r=_imap(1, mv, d, 0, 0), a1_k=_imap(1, d, spec.d_x, 0, 1),
                     a2=_p(a, ao), a2_r=_imap(1, mv, 0, 0, 1), a2_k=_imap(1, d, spec.d_a, 0, 0),
-                    b_k=_imap(1, d, spec.d_out, 0, 1), b_j=_lin(d), c_r=_lin(mw), c_j=_lin(1), alpha=alpha,
+                    b_k=_imap(1, d, mw, 0, n * mw), b_j=_lin(1), c_r=_lin(mw), c_j=_lin(1), alpha=alpha,
                     tag=b"gemm_fctp_dw",
                 )
                 for xo, mu, ao, mv, oo, mw, d, wo, alpha in spec.instructions
