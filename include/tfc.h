@@ -252,6 +252,17 @@ int tfc_gemm_group(const tfc_gemm_desc* descs, int32_t n_descs, tfc_stream_t str
  * Split sums are deterministic: partial tiles are stored and added in a fixed order. */
 int64_t tfc_gemm_workspace_floats(int64_t m, int64_t n, int64_t k);
 
+/* The radial FullyConnectedNet forward (eigenn/nn/utils.py:247-252,262) in ONE launch:
+ *     h_0 = x [n_rows, dims[0]];  h_{i+1} = act_cst * ssp(h_i W_i / sqrt(dims[i]))  (i < n_layers - 1);
+ *     out = h_L W_L / sqrt(dims[L]),  L = n_layers - 1,  W_i row-major [dims[i], dims[i+1]].
+ * `weights` and `hidden` are HOST arrays of device pointers; hidden[i] [n_rows, dims[i+1]] receives
+ * the output of layer i (what backward needs; i < n_layers - 1).  The hidden activations stay in
+ * LDS between layers.  TFC_EUNSUPPORTED (use tfc_gemm layer by layer) unless 2 <= n_layers <= 6,
+ * dims[0 .. n_layers-1] <= 64 and dims[n_layers] % 4 == 0. */
+int tfc_radial_mlp_fwd(const float* x, int64_t n_rows, int32_t n_layers, const int32_t* dims,
+                       const float* const* weights, float act_cst, float* const* hidden, float* out,
+                       tfc_stream_t stream);
+
 /* Channel-contiguous copy of feature rows, for the operands of the dense contractions above:
  * e3nn stores a block as [mul][2l+1] (eigenn feature layout, see the conventions at the top), which
  * gives the contraction index u of o3.Linear / FullyConnectedTensorProduct the stride 2l+1; block b

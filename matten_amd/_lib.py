@@ -115,6 +115,7 @@ SIGNATURES = {
     "tfc_gemm": (C.c_int, [C.POINTER(GemmDesc), _P]),
     "tfc_gemm_group": (C.c_int, [C.POINTER(GemmDesc), _I32, _P]),
     "tfc_gemm_workspace_floats": (_I64, [_I64, _I64, _I64]),
+    "tfc_radial_mlp_fwd": (C.c_int, [_P, _I64, _I32, C.POINTER(_I32), C.POINTER(_P), _F, C.POINTER(_P), _P, _P]),
     "tfc_ir_transpose": (C.c_int, [_P, _I64, _I32, C.POINTER(IrBlock), _I32, _P, _P]),
     "tfc_gate_fwd": (C.c_int, [C.POINTER(GateSeg), _I32, _P, _I64, _I32, _I32, _P, _P]),
     "tfc_profile_enable": (C.c_int, [C.c_int]),

@@ -24,6 +24,7 @@
 #include "tfc_common.h"
 
 #include <algorithm>
+#include <cstdlib>
 #include <vector>
 
 namespace {
@@ -642,7 +643,8 @@ int launch_group(Group& g, const Flags& f, float* workspace, long workspace_floa
         long work = 0;
         for (int i = 0; i < g.n; ++i)
             work += cdiv(g.p[i].m, bm) * cdiv(g.p[i].n, bn) * cdiv(g.p[i].k, BK);
-        const long len = std::max<long>(8, cdiv(work, 1024));
+        static const long target = getenv("TFC_GEMM_TARGET_BLOCKS") ? atol(getenv("TFC_GEMM_TARGET_BLOCKS")) : 1536;
+        const long len = std::max<long>(8, cdiv(work, target));
         long used = 0;
         for (int i = 0; i < g.n; ++i) {
             Problem& p = g.p[i];

@@ -1,0 +1,232 @@
+// Fused forward of the radial FullyConnectedNet (eigenn/nn/utils.py:247-252, called at :262):
+//
+//     h_0 = edge_embedding [E, B];  h_{i+1} = cst * ssp(h_i W_i / sqrt(dim h_i));  w = h_L W_L / sqrt(dim h_L)
+//
+// One workgroup owns 128 edges for the whole network.  The hidden activations never leave the
+// CU (they live k-major in LDS, exactly the layout the next layer's MFMA A operand wants; a copy
+// goes to HBM once because backward needs it), and the last layer - K = hidden size only, so a
+// stand-alone GEMM would spend most of its time in prologue and epilogue - streams W_L through
+// LDS in 64-column tiles while the 128 x hidden activation tile stays put.  fp32 MFMA
+// (v_mfma_f32_32x32x2_f32: exact fmaf chains).
+//
+// Limits of this kernel (the caller falls back to tfc_gemm otherwise): at least one hidden
+// layer, every input / hidden width <= 64, output width a multiple of 4.
+#include "tfc_common.h"
+
+namespace {
+
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+
+constexpr int MAXL = 6;   // layers
+constexpr int RB = 128;   // edges per workgroup
+constexpr int SA = RB + 4;  // LDS row stride of the activation tile [k][row]
+constexpr int SB = 64 + 4;  // LDS row stride of a weight tile [k][col]
+
+struct MlpArgs {
+    const float* x;
+    const float* w[MAXL];
+    float* hidden[MAXL];  // hidden[i] = output of layer i (i < n_layers - 1), [E, dims[i+1]]
+    float* out;
+    long n_rows;
+    int n_layers;
+    int dims[MAXL + 1];
+    float act_cst;
+};
+
+__device__ __forceinline__ float ssp_act(float v, float cst) {
+    const float sp = v > 20.f ? v : log1pf(expf(v));
+    return cst * (sp - 0.69314718055994530942f);
+}
+
+// stage a weight tile W[k0.., c0 .. c0+63] (row-major [K, ldw]) into LDS as [k][col], zero padded
+__device__ __forceinline__ void stage_weights(const float* __restrict__ W, int K, int ldw, int c0, int ncols,
+                                              float* __restrict__ Bs, int t) {
+    // 64 k x 16 column quads = 1024 float4: 4 per thread
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int c4 = t & 15, k = (t >> 4) + 16 * q;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        const int c = c0 + 4 * c4;
+        if (k < K) {
+            if (c + 3 < ncols && (ldw & 3) == 0) {
+                v = *reinterpret_cast<const float4*>(W + (long)k * ldw + c);
+            } else {
+                if (c + 0 < ncols) v.x = W[(long)k * ldw + c + 0];
+                if (c + 1 < ncols) v.y = W[(long)k * ldw + c + 1];
+                if (c + 2 < ncols) v.z = W[(long)k * ldw + c + 2];
+                if (c + 3 < ncols) v.w = W[(long)k * ldw + c + 3];
+            }
+        }
+        *reinterpret_cast<float4*>(&Bs[k * SB + 4 * c4]) = v;
+    }
+}
+
+__global__ __launch_bounds__(256, 2) void tfc_radial_mlp_fwd_kernel(const MlpArgs a) {
+    __shared__ __attribute__((aligned(16))) float act[64 * SA];     // current activations, [k][row]
+    __shared__ __attribute__((aligned(16))) float wt[2][64 * SB];   // weight tiles, [k][col]
+
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int half = lane >> 5, l31 = lane & 31;
+    const long r0 = (long)blockIdx.x * RB;
+
+    // input tile, k-major (rows past the end re-read the last row; nothing of them is stored)
+    {
+        const int d0 = a.dims[0];
+        for (int i = t; i < RB * 64; i += 256) {
+            const int row = i / 64, k = i - row * 64;
+            long r = r0 + row;
+            r = r < a.n_rows ? r : a.n_rows - 1;
+            act[k * SA + row] = k < d0 ? a.x[r * d0 + k] : 0.f;
+        }
+    }
+    // hidden layers
+    for (int l = 0; l + 1 < a.n_layers; ++l) {
+        const int din = a.dims[l], dout = a.dims[l + 1];
+        stage_weights(a.w[l], din, dout, 0, dout, wt[0], t);
+        __syncthreads();
+        floatx16 acc[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+        const int kp = (din + 1) >> 1;  // k pairs (an odd width reads one zero row of padding)
+        for (int s = 0; s < kp; ++s) {
+            const float b = wt[0][(2 * s + half) * SB + wn * 32 + l31];
+            const float a0 = act[(2 * s + half) * SA + wm * 64 + l31];
+            const float a1 = act[(2 * s + half) * SA + wm * 64 + 32 + l31];
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b, acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b, acc[1], 0, 0, 0);
+        }
+        __syncthreads();  // every wave has read the old activations
+        const float alpha = 1.0f / sqrtf((float)din);
+        const int c = wn * 32 + l31;
+        float* hid = a.hidden[l];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int row = wm * 64 + i * 32 + 8 * g + 4 * half;
+                float4 v;
+                v.x = c < dout ? ssp_act(alpha * acc[i][4 * g + 0], a.act_cst) : 0.f;
+                v.y = c < dout ? ssp_act(alpha * acc[i][4 * g + 1], a.act_cst) : 0.f;
+                v.z = c < dout ? ssp_act(alpha * acc[i][4 * g + 2], a.act_cst) : 0.f;
+                v.w = c < dout ? ssp_act(alpha * acc[i][4 * g + 3], a.act_cst) : 0.f;
+                *reinterpret_cast<float4*>(&act[c * SA + row]) = v;
+                if (c < dout) {
+                    if (r0 + row + 0 < a.n_rows) hid[(r0 + row + 0) * dout + c] = v.x;
+                    if (r0 + row + 1 < a.n_rows) hid[(r0 + row + 1) * dout + c] = v.y;
+                    if (r0 + row + 2 < a.n_rows) hid[(r0 + row + 2) * dout + c] = v.z;
+                    if (r0 + row + 3 < a.n_rows) hid[(r0 + row + 3) * dout + c] = v.w;
+                }
+            }
+        }
+        __syncthreads();
+    }
+    // last layer: stream W_L in 64-column tiles, the activation tile stays in LDS
+    {
+        const int L = a.n_layers - 1;
+        const int din = a.dims[L], W = a.dims[L + 1];
+        const float* __restrict__ wl = a.w[L];
+        const float alpha = 1.0f / sqrtf((float)din);
+        const int kp = (din + 1) >> 1;
+        const int nsteps = (W + 63) / 64;
+        stage_weights(wl, din, W, 0, W, wt[0], t);
+        __syncthreads();
+        for (int n = 0; n < nsteps; ++n) {
+            const int cur = n & 1;
+            // next tile: global -> registers now, registers -> LDS after the MFMAs
+            float4 pre[4];
+            const bool more = n + 1 < nsteps;
+            if (more) {
+                const int c0 = (n + 1) * 64;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int c4 = t & 15, k = (t >> 4) + 16 * q;
+                    const int c = c0 + 4 * c4;
+                    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (k < din && c + 3 < W) v = *reinterpret_cast<const float4*>(wl + (long)k * W + c);
+                    pre[q] = v;
+                }
+            }
+            floatx16 acc[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+            const float* Bs = wt[cur];
+#pragma unroll 8
+            for (int s = 0; s < kp; ++s) {
+                const float b = Bs[(2 * s + half) * SB + wn * 32 + l31];
+                const float a0 = act[(2 * s + half) * SA + wm * 64 + l31];
+                const float a1 = act[(2 * s + half) * SA + wm * 64 + 32 + l31];
+                acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b, acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b, acc[1], 0, 0, 0);
+            }
+            if (more) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int c4 = t & 15, k = (t >> 4) + 16 * q;
+                    *reinterpret_cast<float4*>(&wt[cur ^ 1][k * SB + 4 * c4]) = pre[q];
+                }
+            }
+            const int c = n * 64 + wn * 32 + l31;
+            if (c < W) {
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int reg = 0; reg < 16; ++reg) {
+                        const long row = r0 + wm * 64 + i * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * half;
+                        if (row < a.n_rows) a.out[row * W + c] = alpha * acc[i][reg];
+                    }
+            }
+            __syncthreads();
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int tfc_radial_mlp_fwd(const float* x, int64_t n_rows, int32_t n_layers, const int32_t* dims,
+                                  const float* const* weights, float act_cst, float* const* hidden, float* out,
+                                  tfc_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    TFC_REQUIRE(n_rows >= 0, TFC_EINVAL, "tfc_radial_mlp_fwd: negative row count");
+    TFC_REQUIRE(dims && weights && hidden, TFC_EINVAL, "tfc_radial_mlp_fwd: null table");
+    TFC_REQUIRE(n_layers >= 2 && n_layers <= MAXL, TFC_EUNSUPPORTED,
+                "tfc_radial_mlp_fwd: %d layers (this kernel takes 2..%d)", n_layers, MAXL);
+    for (int i = 0; i <= n_layers; ++i) TFC_REQUIRE(dims[i] > 0, TFC_EINVAL, "tfc_radial_mlp_fwd: width %d", dims[i]);
+    for (int i = 0; i < n_layers; ++i)
+        TFC_REQUIRE(dims[i] <= 64, TFC_EUNSUPPORTED, "tfc_radial_mlp_fwd: input/hidden width %d > 64", dims[i]);
+    TFC_REQUIRE(dims[n_layers] % 4 == 0, TFC_EUNSUPPORTED, "tfc_radial_mlp_fwd: output width %d not a multiple of 4",
+                dims[n_layers]);
+    if (n_rows == 0) return TFC_OK;
+    TFC_REQUIRE(x && out, TFC_EINVAL, "tfc_radial_mlp_fwd: null tensor");
+    TFC_REQUIRE(((uintptr_t)weights[n_layers - 1] & 15) == 0, TFC_EUNSUPPORTED,
+                "tfc_radial_mlp_fwd: last weight matrix not 16-byte aligned");
+    MlpArgs a;
+    a.x = x;
+    a.out = out;
+    a.n_rows = n_rows;
+    a.n_layers = n_layers;
+    a.act_cst = act_cst;
+    for (int i = 0; i < MAXL; ++i) {
+        a.w[i] = nullptr;
+        a.hidden[i] = nullptr;
+    }
+    for (int i = 0; i <= n_layers; ++i) a.dims[i] = dims[i];
+    for (int i = 0; i < n_layers; ++i) {
+        TFC_REQUIRE(weights[i], TFC_EINVAL, "tfc_radial_mlp_fwd: null weight %d", i);
+        a.w[i] = weights[i];
+        if (i + 1 < n_layers) {
+            TFC_REQUIRE(hidden[i], TFC_EINVAL, "tfc_radial_mlp_fwd: null hidden buffer %d", i);
+            a.hidden[i] = hidden[i];
+        }
+    }
+    const long nb = (n_rows + RB - 1) / RB;
+    TFC_REQUIRE(nb < (1LL << 31), TFC_EUNSUPPORTED, "tfc_radial_mlp_fwd: grid too large");
+    TfcProfScope prof("mlp_fused_fwd", stream);
+    tfc_radial_mlp_fwd_kernel<<<(unsigned)nb, 256, 0, stream>>>(a);
+    TFC_LAUNCH_CHECK("tfc_radial_mlp_fwd_kernel");
+    return TFC_OK;
+}

@@ -635,18 +635,30 @@ class _RadialMlpFn(torch.autograd.Function):
         ws = [_f32(w, "mlp weight") for w in weights]
         E = x.shape[0]
         hs = [x]
+        dims = [x.shape[1]] + [w.shape[1] for w in ws]
         for i, w in enumerate(ws):
-            hin, hout = w.shape
-            if hs[-1].shape[1] != hin:
-                raise ValueError(f"radial mlp: layer {i} expects {hin} inputs, got {hs[-1].shape[1]}")
-            out = torch.empty(E, hout, dtype=torch.float32, device=x.device)
-            last = i == len(ws) - 1
-            _gemm(
-                E, hout, hin, _p(hs[-1]), _p(w), _p(out), a1_r=_lin(hin), a1_k=_lin(1), b_k=_lin(hout), b_j=_lin(1),
-                c_r=_lin(hout), c_j=_lin(1), alpha=1.0 / math.sqrt(hin),
-                epilogue=_lib.EPI_NONE if last else _lib.EPI_SSP, act_cst=act_cst, tag=b"gemm_mlp_fwd",
-            )
-            hs.append(out)
+            if w.shape[0] != dims[i]:
+                raise ValueError(f"radial mlp: layer {i} expects {w.shape[0]} inputs, got {dims[i]}")
+        nl = len(ws)
+        if 2 <= nl <= 6 and max(dims[:-1]) <= 64 and dims[-1] % 4 == 0 and ws[-1].data_ptr() % 16 == 0:
+            # whole network in one launch, hidden activations kept in LDS (tfc_radial_mlp_fwd)
+            outs = [torch.empty(E, d, dtype=torch.float32, device=x.device) for d in dims[1:]]
+            c_dims = (C.c_int32 * (nl + 1))(*dims)
+            c_w = (C.c_void_p * nl)(*[w.data_ptr() for w in ws])
+            c_h = (C.c_void_p * nl)(*([o.data_ptr() for o in outs[:-1]] + [None]))
+            _lib.check(_lib.lib().tfc_radial_mlp_fwd(_ptr(x), E, nl, c_dims, c_w, float(act_cst), c_h, _ptr(outs[-1]), _stream()))
+            hs += outs
+        else:
+            for i, w in enumerate(ws):
+                hin, hout = w.shape
+                out = torch.empty(E, hout, dtype=torch.float32, device=x.device)
+                last = i == nl - 1
+                _gemm(
+                    E, hout, hin, _p(hs[-1]), _p(w), _p(out), a1_r=_lin(hin), a1_k=_lin(1), b_k=_lin(hout), b_j=_lin(1),
+                    c_r=_lin(hout), c_j=_lin(1), alpha=1.0 / math.sqrt(hin),
+                    epilogue=_lib.EPI_NONE if last else _lib.EPI_SSP, act_cst=act_cst, tag=b"gemm_mlp_fwd",
+                )
+                hs.append(out)
         ctx.save_for_backward(*hs[:-1], *ws)
         ctx.n_layers, ctx.act_cst = len(ws), float(act_cst)
         return hs[-1]
