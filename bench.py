@@ -52,6 +52,23 @@ def conv_layer_bytes(layer, n_nodes, n_edges):
     return b_fwd * n_edges, b_bwd * n_edges, dict(d_in=d_in, s=s, d_mid=d_mid, w=w)
 
 
+def pmc_traffic(workload):
+    """HBM bytes per conv-backward launch from the committed rocprofv3 PMC passes of this same
+    command (FETCH_SIZE and WRITE_SIZE in separate runs, corrected with the calibration launches of
+    tools/pmc_calibrate.py as MI355X_MICROARCH.md prescribes; tools/pmc_traffic.py).  None when no
+    such profile is committed for the workload."""
+    import glob
+
+    hits = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", f"pmc_traffic_{workload}.json")))
+    if not hits:
+        return None
+    try:
+        with open(hits[-1]) as f:
+            return float(json.load(f)["kernels"]["tfc_conv_bwd_kernel"]["avg_bytes_per_launch"])
+    except Exception:
+        return None
+
+
 def build_batch(wl, rank, device):
     from matten_amd.data.crystal import synthetic_batch
     from matten_amd.harness import species_index
@@ -218,7 +235,7 @@ def main():
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": ach / HBM_PEAK_GBS,
-                "traffic": None,
+                "traffic": pmc_traffic(args.workload),
                 "bytes_per_launch": bytes_per_launch,
                 "avg_launch_ms": tot / c,
             }

@@ -670,16 +670,19 @@ class _RadialMlpFn(torch.autograd.Function):
         g = _f32(g, "grad_output")
         E = g.shape[0]
         dws: List[Optional[torch.Tensor]] = [None] * L
+        dw_descs = []
+        keep = []  # gradients the deferred weight-gradient launch still reads
         for i in range(L - 1, -1, -1):
             w, h = ws[i], hs[i]
             hin, hout = w.shape
             alpha = 1.0 / math.sqrt(hin)
             if ctx.needs_input_grad[2 + i]:
                 dw = torch.empty_like(w)
-                _gemm(
+                dw_descs.append(_desc(
                     hin, hout, E, _p(h), _p(g), _p(dw), a1_r=_lin(1), a1_k=_lin(hin), b_k=_lin(hout), b_j=_lin(1),
                     c_r=_lin(hout), c_j=_lin(1), alpha=alpha, tag=b"gemm_mlp_dw",
-                )
+                ))
+                keep.append(g)
                 dws[i] = dw
             if i > 0 or ctx.needs_input_grad[0]:
                 dh = torch.empty(E, hin, dtype=torch.float32, device=g.device)
@@ -692,6 +695,9 @@ class _RadialMlpFn(torch.autograd.Function):
                 g = dh
             else:
                 g = None
+        # all weight gradients (h_i^T g_i, K = number of edges) in one grouped launch
+        _gemm_group(dw_descs)
+        del keep
         return (g if ctx.needs_input_grad[0] else None, None, *dws)
 
 
