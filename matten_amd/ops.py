@@ -565,6 +565,10 @@ class LinearSpec:
 
 
 class _LinearFn(torch.autograd.Function):
+    """o3.Linear on channel-contiguous copies of its input and of the output gradient
+    (tfc_ir_transpose): every instruction, whatever its l, is then the same plain contraction over
+    channels, and all of them share one grouped launch."""
+
     @staticmethod
     def forward(ctx, x, weight, spec: LinearSpec):
         x, weight = _f32(x, "x"), _f32(weight, "weight")
@@ -573,34 +577,36 @@ class _LinearFn(torch.autograd.Function):
             raise ValueError(f"linear: x{tuple(x.shape)} / weight[{weight.numel()}] do not match the irreps ({spec.d_in}, {spec.weight_numel})")
         alloc = torch.empty if spec.out_covered else torch.zeros
         out = alloc(n, spec.d_out, dtype=torch.float32, device=x.device)
+        xt = _ir_transpose(x, [(in_off, mi, d) for in_off, mi, _, _, d, _, _ in spec.instructions])
+
         def fwd(in_off, mi, out_off, mo, d, w_off, pw):
             return lambda acc: _desc(
-                n * d, mo, mi, _p(x, in_off), _p(weight, w_off), _p(out, out_off),
-                a1_r=_imap(1, d, spec.d_in, 0, 1), a1_k=_lin(d), b_k=_lin(mo), b_j=_lin(1),
+                n * d, mo, mi, _p(xt, in_off * n), _p(weight, w_off), _p(out, out_off),
+                a1_r=_imap(1, d, mi, 0, n * mi), a1_k=_lin(1), b_k=_lin(mo), b_j=_lin(1),
                 c_r=_imap(1, d, spec.d_out, 0, 1), c_j=_lin(d), alpha=pw, accumulate=acc,
                 tag=b"gemm_linear_fwd",
             )
 
         _gemm_waves([(ins[2], fwd(*ins)) for ins in spec.instructions])
-        ctx.save_for_backward(x, weight)
-        ctx.spec = spec
+        ctx.save_for_backward(xt, weight)
+        ctx.spec, ctx.n = spec, n
         return out
 
     @staticmethod
     def backward(ctx, g):
-        x, weight = ctx.saved_tensors
-        spec = ctx.spec
+        xt, weight = ctx.saved_tensors
+        spec, n = ctx.spec, ctx.n
         g = _f32(g, "grad_output")
-        n = x.shape[0]
         dx = dw = None
+        gt = _ir_transpose(g, [(out_off, mo, d) for _, _, out_off, mo, d, _, _ in spec.instructions])
         if ctx.needs_input_grad[0]:
             alloc = torch.empty if spec.in_covered else torch.zeros
-            dx = alloc(n, spec.d_in, dtype=torch.float32, device=x.device)
+            dx = alloc(n, spec.d_in, dtype=torch.float32, device=g.device)
 
             def bdx(in_off, mi, out_off, mo, d, w_off, pw):
                 return lambda acc: _desc(
-                    n * d, mi, mo, _p(g, out_off), _p(weight, w_off), _p(dx, in_off),
-                    a1_r=_imap(1, d, spec.d_out, 0, 1), a1_k=_lin(d), b_k=_lin(1), b_j=_lin(mo),
+                    n * d, mi, mo, _p(gt, out_off * n), _p(weight, w_off), _p(dx, in_off),
+                    a1_r=_imap(1, d, mo, 0, n * mo), a1_k=_lin(1), b_k=_lin(1), b_j=_lin(mo),
                     c_r=_imap(1, d, spec.d_in, 0, 1), c_j=_lin(d), alpha=pw, accumulate=acc,
                     tag=b"gemm_linear_dx",
                 )
@@ -610,8 +616,8 @@ class _LinearFn(torch.autograd.Function):
             dw = torch.empty_like(weight)
             _gemm_group([
                 _desc(
-                    mi, mo, n * d, _p(x, in_off), _p(g, out_off), _p(dw, w_off),
-                    a1_r=_lin(d), a1_k=_imap(1, d, spec.d_in, 0, 1), b_k=_imap(1, d, spec.d_out, 0, 1), b_j=_lin(d),
+                    mi, mo, n * d, _p(xt, in_off * n), _p(gt, out_off * n), _p(dw, w_off),
+                    a1_r=_lin(1), a1_k=_imap(1, d, mi, 0, n * mi), b_k=_imap(1, d, mo, 0, n * mo), b_j=_lin(1),
                     c_r=_lin(mo), c_j=_lin(1), alpha=pw, tag=b"gemm_linear_dw",
                 )
                 for in_off, mi, out_off, mo, d, w_off, pw in spec.instructions
