@@ -729,9 +729,120 @@ class FctpSpec:
     a_covered: bool
 
 
+def _fctp_fwd(n, x, a, d_a, weight, out, spec, ins_list, on_base):
+    """out[(n,k), w] (+)= alpha sum_{(u,v)} x[n,u,k] a[n,v] W[(u,v), w] for every instruction."""
+    def fwd(xo, mu, ao, mv, oo, mw, d, wo, alpha):
+        return lambda acc: _desc(
+            n * d, mw, mu * mv, _p(x, xo), _p(weight, wo), _p(out, oo),
+            a1_r=_imap(1, d, spec.d_x, 0, 1), a1_k=_imap(1, mv, d, 0, 0),
+            a2=_p(a, ao), a2_r=_imap(1, d, d_a, 0, 0), a2_k=_imap(1, mv, 0, 0, 1),
+            b_k=_lin(mw), b_j=_lin(1), c_r=_imap(1, d, spec.d_out, 0, 1), c_j=_lin(d), alpha=alpha,
+            accumulate=acc or on_base, tag=b"gemm_fctp_fwd",
+        )
+
+    _gemm_waves([(ins[4], fwd(*ins)) for ins in ins_list])
+
+
+def _fctp_dx(n, a, d_a, weight, gt, dx, spec, ins_list):
+    """dx[(n,k), u] = alpha sum_{(v,w)} a[n,v] g[n,w,k] W[u,v,w]   (gt: channel-contiguous g)"""
+    def bdx(xo, mu, ao, mv, oo, mw, d, wo, alpha):
+        return lambda acc: _desc(
+            n * d, mu, mv * mw, _p(a, ao), _p(weight, wo), _p(dx, xo),
+            a1_r=_imap(1, d, d_a, 0, 0), a1_k=_imap(1, mw, 1, 0, 0),
+            a2=_p(gt, oo * n), a2_r=_imap(1, d, mw, 0, n * mw), a2_k=_imap(1, mw, 0, 0, 1),
+            b_k=_lin(1), b_j=_lin(mv * mw), c_r=_imap(1, d, spec.d_x, 0, 1), c_j=_lin(d), alpha=alpha,
+            accumulate=acc, tag=b"gemm_fctp_dx",
+        )
+
+    _gemm_waves([(ins[0], bdx(*ins)) for ins in ins_list])
+
+
+def _fctp_da(n, xt, weight, gt, spec, ins_list, d_a, a_covered):
+    """da[n, v] = alpha sum_{(k,u,w)} x[n,u,k] g[n,w,k] W[u,v,w].  Every instruction adds to the same
+    block of `da`: each writes its own partial [N, mul_v] in one grouped launch, and the partials
+    are then summed in instruction order (deterministic)."""
+    ni = len(ins_list)
+    part = torch.empty(ni, n, d_a, dtype=torch.float32, device=xt.device)
+    if not a_covered or any(ins[3] != d_a for ins in ins_list):
+        part.zero_()
+    _gemm_group([
+        _desc(
+            n, mv, d * mu * mw, _p(xt, xo * n), _p(weight, wo), _p(part, i * n * d_a + ao),
+            a1_r=_lin(mu), a1_k=_imap(mu, mw, n * mu, 1, 0),
+            a2=_p(gt, oo * n), a2_r=_lin(mw), a2_k=_imap(mu, mw, n * mw, 0, 1),
+            b_k=_imap(mu, mw, 0, mv * mw, 1), b_j=_lin(mw), c_r=_lin(d_a), c_j=_lin(1), alpha=alpha,
+            tag=b"gemm_fctp_da",
+        )
+        for i, (xo, mu, ao, mv, oo, mw, d, wo, alpha) in enumerate(ins_list)
+    ])
+    return part.sum(dim=0) if ni > 1 else part[0]
+
+
+def _fctp_dw(n, x, a, d_a, gt, dw, spec, ins_list):
+    """dW[(u,v), w] = alpha sum_{(n,k)} x[n,u,k] a[n,v] g[n,w,k]"""
+    _gemm_group([
+        _desc(
+            mu * mv, mw, n * d, _p(x, xo), _p(gt, oo * n), _p(dw, wo),
+            a1_r=_imap(1, mv, d, 0, 0), a1_k=_imap(1, d, spec.d_x, 0, 1),
+            a2=_p(a, ao), a2_r=_imap(1, mv, 0, 0, 1), a2_k=_imap(1, d, d_a, 0, 0),
+            b_k=_imap(1, d, mw, 0, n * mw), b_j=_lin(1), c_r=_lin(mw), c_j=_lin(1), alpha=alpha,
+            tag=b"gemm_fctp_dw",
+        )
+        for xo, mu, ao, mv, oo, mw, d, wo, alpha in ins_list
+    ])
+
+
+_ATTR_FACTORS: "dict[tuple, tuple]" = {}
+
+
+def attr_factors(a: torch.Tensor):
+    """(C [N, r], R [r, d_a]) with a == C @ R exactly, when the rows of `a` are copies of a few distinct
+    rows (node attributes that are a species embedding: eigenn/nn/embedding.py:59-75 sets NODE_ATTRS
+    to embedding(species), so at most n_species distinct rows) - else None.  C is the one-hot matrix
+    of the row classes, R the distinct rows (zero padded to r, a multiple of 4).  Costs two host
+    syncs, paid once per tensor: the result is cached on (address, version) with the tensor held
+    alive, so the layers of a model, forward and backward, share it."""
+    key = (a.data_ptr(), a._version, tuple(a.shape))
+    hit = _ATTR_FACTORS.get(key)
+    if hit is not None:
+        return hit[1]
+    n, d_a = a.shape
+    res = None
+    if n >= 64 and d_a >= 8 and a.is_contiguous():
+        with torch.no_grad():
+            gen = torch.Generator().manual_seed(0x5EED)
+            coef = (torch.randint(1, 1 << 40, (d_a,), generator=gen, dtype=torch.int64) * 2 + 1).to(a.device)
+            h = (a.detach().view(torch.int32).to(torch.int64) * coef).sum(dim=1)
+            uniq, inv = torch.unique(h, return_inverse=True)  # sync
+            u = int(uniq.numel())
+            r = max(4, (u + 3) // 4 * 4)
+            if 2 * r <= d_a:
+                rep = torch.full((u,), n, dtype=torch.int64, device=a.device)
+                rep.scatter_reduce_(0, inv, torch.arange(n, device=a.device), reduce="amin")
+                rows = a.detach()[rep]
+                if bool((rows[inv] == a.detach()).all().item()):  # sync; also rejects NaN rows
+                    R = torch.zeros(r, d_a, dtype=torch.float32, device=a.device)
+                    R[:u] = rows
+                    Cm = torch.zeros(n, r, dtype=torch.float32, device=a.device)
+                    Cm[torch.arange(n, device=a.device), inv] = 1.0
+                    res = (Cm, R)
+    if len(_ATTR_FACTORS) >= 8:
+        _ATTR_FACTORS.pop(next(iter(_ATTR_FACTORS)))
+    _ATTR_FACTORS[key] = (a, res)
+    return res
+
+
 class _FctpFn(torch.autograd.Function):
+    """FullyConnectedTensorProduct(x, a) with scalar second input (the self connection).
+
+    Dense route: one contraction over (u, v) per instruction.  Low-rank route (`factors` =
+    attr_factors(a) = (C, R), a = C R): the same product is FCTP(x, C; W') with
+    W'[u,s,w] = sum_v R[s,v] W[u,v,w], whose contraction index (u, s) is d_a / r times shorter; the
+    forward, dx and dW take it, da is per node and stays dense.  Both routes are exact
+    re-associations of the same sums."""
+
     @staticmethod
-    def forward(ctx, x, a, weight, spec: FctpSpec, base):
+    def forward(ctx, x, a, weight, spec: FctpSpec, base, factors):
         x, a, weight = _f32(x, "x"), _f32(a, "node_attrs"), _f32(weight, "weight")
         n = x.shape[0]
         if x.shape[1] != spec.d_x or a.shape[1] != spec.d_a or weight.numel() != spec.weight_numel:
@@ -746,27 +857,42 @@ class _FctpFn(torch.autograd.Function):
             alloc = torch.empty if spec.out_covered else torch.zeros
             out = alloc(n, spec.d_out, dtype=torch.float32, device=x.device)
             on_base = False
-
-        def fwd(xo, mu, ao, mv, oo, mw, d, wo, alpha):
-            return lambda acc: _desc(
-                n * d, mw, mu * mv, _p(x, xo), _p(weight, wo), _p(out, oo),
-                a1_r=_imap(1, d, spec.d_x, 0, 1), a1_k=_imap(1, mv, d, 0, 0),
-                a2=_p(a, ao), a2_r=_imap(1, d, spec.d_a, 0, 0), a2_k=_imap(1, mv, 0, 0, 1),
-                b_k=_lin(mw), b_j=_lin(1), c_r=_imap(1, d, spec.d_out, 0, 1), c_j=_lin(d), alpha=alpha,
-                accumulate=acc or on_base, tag=b"gemm_fctp_fwd",
-            )
-
-        _gemm_waves([(ins[4], fwd(*ins)) for ins in spec.instructions])
-        ctx.save_for_backward(x, a, weight)
+        if factors is None:
+            _fctp_fwd(n, x, a, spec.d_a, weight, out, spec, spec.instructions, on_base)
+            ctx.save_for_backward(x, a, weight)
+            ctx.low = None
+        else:
+            Cm, R = factors
+            r = Cm.shape[1]
+            # W'[u, s, w] = sum_v R[s, v] W[u, v, w], per instruction
+            low_ins, off = [], 0
+            for xo, mu, ao, mv, oo, mw, d, wo, alpha in spec.instructions:
+                low_ins.append((xo, mu, 0, r, oo, mw, d, off, alpha))
+                off += mu * r * mw
+            wp = torch.empty(max(off, 1), dtype=torch.float32, device=x.device)
+            _gemm_group([
+                _desc(
+                    r, mu * mw, mv, _p(R, ao), _p(weight, wo), _p(wp, lo[7]),
+                    a1_r=_lin(spec.d_a), a1_k=_lin(1), b_k=_lin(mw), b_j=_imap(1, mw, mv * mw, 0, 1),
+                    c_r=_lin(mw), c_j=_imap(1, mw, r * mw, 0, 1), tag=b"gemm_fctp_lowrank_w",
+                )
+                for (xo, mu, ao, mv, oo, mw, d, wo, alpha), lo in zip(spec.instructions, low_ins)
+            ])
+            _fctp_fwd(n, x, Cm, r, wp, out, spec, low_ins, on_base)
+            ctx.save_for_backward(x, a, weight, Cm, R, wp)
+            ctx.low = tuple(low_ins)
         ctx.spec = spec
         ctx.has_base = base is not None
         return out
 
     @staticmethod
     def backward(ctx, g):
-        x, a, weight = ctx.saved_tensors
         spec = ctx.spec
         g = _f32(g, "grad_output")
+        if ctx.low is None:
+            x, a, weight = ctx.saved_tensors
+        else:
+            x, a, weight, Cm, R, wp = ctx.saved_tensors
         n = x.shape[0]
         dx = da = dw = None
         # channel-contiguous copies ([dim][N][mul] per block): the contractions below all run over
@@ -774,58 +900,39 @@ class _FctpFn(torch.autograd.Function):
         gt = _ir_transpose(g, [(oo, mw, d) for _, _, _, _, oo, mw, d, _, _ in spec.instructions])
         if ctx.needs_input_grad[0]:
             dx = (torch.empty if spec.x_covered else torch.zeros)(n, spec.d_x, dtype=torch.float32, device=x.device)
-
-            def bdx(xo, mu, ao, mv, oo, mw, d, wo, alpha):
-                # dx[(n,k), u] = sum_{(v,w)} a[n,v] g[n,w,k] W[u,v,w]
-                return lambda acc: _desc(
-                    n * d, mu, mv * mw, _p(a, ao), _p(weight, wo), _p(dx, xo),
-                    a1_r=_imap(1, d, spec.d_a, 0, 0), a1_k=_imap(1, mw, 1, 0, 0),
-                    a2=_p(gt, oo * n), a2_r=_imap(1, d, mw, 0, n * mw), a2_k=_imap(1, mw, 0, 0, 1),
-                    b_k=_lin(1), b_j=_lin(mv * mw), c_r=_imap(1, d, spec.d_x, 0, 1), c_j=_lin(d), alpha=alpha,
-                    accumulate=acc, tag=b"gemm_fctp_dx",
-                )
-
-            _gemm_waves([(ins[0], bdx(*ins)) for ins in spec.instructions])
+            if ctx.low is None:
+                _fctp_dx(n, a, spec.d_a, weight, gt, dx, spec, spec.instructions)
+            else:
+                _fctp_dx(n, Cm, Cm.shape[1], wp, gt, dx, spec, ctx.low)
         if ctx.needs_input_grad[1]:
-            # da[n, v] = sum_{(k,u,w)} x[n,u,k] g[n,w,k] W[u,v,w].  Every instruction adds to the same
-            # block of `da`: each writes its own partial [N, mul_v] in one grouped launch, and the
-            # partials are then summed in instruction order (deterministic).
             xt = _ir_transpose(x, [(xo, mu, d) for xo, mu, _, _, _, _, d, _, _ in spec.instructions])
-            ni = len(spec.instructions)
-            part = torch.empty(ni, n, spec.d_a, dtype=torch.float32, device=x.device)
-            if not spec.a_covered or any(ins[3] != spec.d_a for ins in spec.instructions):
-                part.zero_()
-            _gemm_group([
-                _desc(
-                    n, mv, d * mu * mw, _p(xt, xo * n), _p(weight, wo), _p(part, i * n * spec.d_a + ao),
-                    a1_r=_lin(mu), a1_k=_imap(mu, mw, n * mu, 1, 0),
-                    a2=_p(gt, oo * n), a2_r=_lin(mw), a2_k=_imap(mu, mw, n * mw, 0, 1),
-                    b_k=_imap(mu, mw, 0, mv * mw, 1), b_j=_lin(mw), c_r=_lin(spec.d_a), c_j=_lin(1), alpha=alpha,
-                    tag=b"gemm_fctp_da",
-                )
-                for i, (xo, mu, ao, mv, oo, mw, d, wo, alpha) in enumerate(spec.instructions)
-            ])
-            da = part.sum(dim=0) if ni > 1 else part[0]
+            da = _fctp_da(n, xt, weight, gt, spec, spec.instructions, spec.d_a, spec.a_covered)
         if ctx.needs_input_grad[2]:
             dw = torch.empty_like(weight)
-            # dW[(u,v), w] = sum_{(n,k)} x[n,u,k] a[n,v] g[n,w,k]
-            _gemm_group([
-                _desc(
-                    mu * mv, mw, n * d, _p(x, xo), _p(gt, oo * n), _p(dw, wo),
-                    a1_r=_imap(1, mv, d, 0, 0), a1_k=_imap(1, d, spec.d_x, 0, 1),
-                    a2=_p(a, ao), a2_r=_imap(1, mv, 0, 0, 1), a2_k=_imap(1, d, spec.d_a, 0, 0),
-                    b_k=_imap(1, d, mw, 0, n * mw), b_j=_lin(1), c_r=_lin(mw), c_j=_lin(1), alpha=alpha,
-                    tag=b"gemm_fctp_dw",
-                )
-                for xo, mu, ao, mv, oo, mw, d, wo, alpha in spec.instructions
-            ])
-        return dx, da, dw, None, (g if ctx.has_base else None)
+            if ctx.low is None:
+                _fctp_dw(n, x, a, spec.d_a, gt, dw, spec, spec.instructions)
+            else:
+                r = Cm.shape[1]
+                dwp = torch.empty_like(wp)
+                _fctp_dw(n, x, Cm, r, gt, dwp, spec, ctx.low)
+                # dW[u, v, w] = sum_s R[s, v] dW'[u, s, w]
+                _gemm_group([
+                    _desc(
+                        mv, mu * mw, r, _p(R, ao), _p(dwp, lo[7]), _p(dw, wo),
+                        a1_r=_lin(1), a1_k=_lin(spec.d_a), b_k=_lin(mw), b_j=_imap(1, mw, r * mw, 0, 1),
+                        c_r=_lin(mw), c_j=_imap(1, mw, mv * mw, 0, 1), tag=b"gemm_fctp_lowrank_w",
+                    )
+                    for (xo, mu, ao, mv, oo, mw, d, wo, alpha), lo in zip(spec.instructions, ctx.low)
+                ])
+        return dx, da, dw, None, (g if ctx.has_base else None), None
 
 
-def fctp(x, a, weight, spec: FctpSpec, base: Optional[torch.Tensor] = None):
+def fctp(x, a, weight, spec: FctpSpec, base: Optional[torch.Tensor] = None, low_rank: bool = True):
     """FullyConnectedTensorProduct(x, a) with scalar `a`; when `base` is given the result is
-    accumulated into it in place (out = base + fctp), saving the separate add."""
-    return _FctpFn.apply(x, a, weight, spec, base)
+    accumulated into it in place (out = base + fctp), saving the separate add.  `low_rank`: take the
+    shorter contraction when the rows of `a` are copies of a few distinct rows (attr_factors)."""
+    factors = attr_factors(a) if low_rank else None
+    return _FctpFn.apply(x, a, weight, spec, base, factors)
 
 
 # ------------------------------------------------------------------ Gate

@@ -152,6 +152,43 @@ def test_fctp_vs_oracle(device, in1, in2, out):
     assert rel(y2g, y2) < TOL
 
 
+@pytest.mark.parametrize("n_distinct", [1, 3, 5, 17])
+def test_fctp_low_rank_route_vs_oracle(device, n_distinct):
+    """Node attributes that are copies of a few distinct rows (a species embedding) take the
+    shorter contraction (ops.attr_factors); every gradient, the per-node one of the attributes
+    included, must still be the dense one."""
+    from matten_amd import ops
+    from matten_amd.nn.e3 import FullyConnectedTensorProduct
+    from oracle import e3ref
+
+    in1, in2, out = "16x0e+8x1o+8x2e", "32x0e", "16x0o+40x0e+8x1o+8x1e+8x2o+8x2e"
+    torch.manual_seed(11)
+    o = e3ref.FullyConnectedTensorProduct(in1, in2, out).double()
+    h = FullyConnectedTensorProduct(in1, in2, out)
+    _pair_state(o, h)
+    h = h.to(device)
+    n = 203
+    table = torch.randn(n_distinct, 32, dtype=torch.float64)
+    idx = torch.randint(0, n_distinct, (n,))
+    x = torch.randn(n, o.irreps_in1.dim, dtype=torch.float64, requires_grad=True)
+    a = table[idx].clone().requires_grad_(True)
+    base = torch.randn(n, o.irreps_out.dim, dtype=torch.float64, requires_grad=True)
+    xg, ag, bg = (t.detach().float().to(device).requires_grad_(True) for t in (x, a, base))
+    f = ops.attr_factors(ag)
+    if 2 * max(4, (n_distinct + 3) // 4 * 4) <= 32:
+        assert f is not None and torch.equal(f[0] @ f[1], ag.detach())
+    else:
+        assert f is None
+    y = base + o(x, a)
+    yg = h(xg, ag, base=bg * 1.0)
+    assert rel(yg, y) < TOL
+    go = torch.randn_like(y)
+    ref = torch.autograd.grad(y, [x, a, o.weight, base], go)
+    got = torch.autograd.grad(yg, [xg, ag, h.weight, bg], go.float().to(device))
+    for r, g_ in zip(ref, got):
+        assert rel(g_, r) < TOL
+
+
 @pytest.mark.parametrize("hs", [[8, 64, 64, 96], [8, 64, 384], [4, 8, 24], [8, 64, 64, 1728]])
 def test_radial_mlp_vs_oracle(device, hs):
     from matten_amd.nn.e3 import FullyConnectedNet
