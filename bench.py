@@ -193,7 +193,7 @@ def main():
     sync()
     L = _lib.lib()
     L.tfc_profile_reset()
-    L.tfc_profile_enable(1)
+    L.tfc_profile_enable(2)  # HIP events around the conv kernels only, on their launch stream
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
@@ -201,6 +201,16 @@ def main():
     elapsed = time.perf_counter() - t0
     L.tfc_profile_enable(0)
     prof = _lib.profile_report()
+    # per-kernel breakdown of a step (informational; outside the timed region)
+    L.tfc_profile_reset()
+    L.tfc_profile_enable(1)
+    n_break = 3
+    for _ in range(n_break):
+        step()
+    sync()
+    L.tfc_profile_enable(0)
+    prof_all = _lib.profile_report()
+    L.tfc_profile_reset()
 
     t = torch.tensor([elapsed], dtype=torch.float64, device=device)
     e = torch.tensor([float(n_edges)], dtype=torch.float64, device=device)
@@ -220,7 +230,7 @@ def main():
             fb += f
             bb += b
             shapes.append(sh)
-        kern = {k: {"launches": c, "avg_ms": tot / c} for k, (c, tot) in prof.items()}
+        kern = {k: {"launches_per_step": c / n_break, "avg_ms": tot / c} for k, (c, tot) in prof_all.items()}
         n_layers = len(model.convs)
         roof = None
         if "tfc_conv_bwd_kernel" in prof:

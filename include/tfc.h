@@ -310,7 +310,9 @@ int tfc_gate_bwd(const tfc_gate_seg* segs, int32_t n_segs, const float* x, const
  * HIP events on its own stream.  tfc_profile_report() synchronises on those events and writes
  * one "kernel_name launches total_ms" line per kernel into `buf`; it returns the number of
  * lines (>= 0) or a negative TFC_E* code.  This is the library's only global mutable state
- * besides the error string (mutex protected); off by default.
+ * besides the error string (mutex protected); off by default.  tfc_profile_enable(1) times every
+ * kernel, (2) only the convolution kernels (tfc_conv_*: two event records per launch are a
+ * measurable host cost when hundreds of short kernels run per step), (0) none.
  */
 int tfc_profile_enable(int on);
 int tfc_profile_reset(void);

@@ -643,14 +643,15 @@ int launch_group(Group& g, const Flags& f, float* workspace, long workspace_floa
         long work = 0;
         for (int i = 0; i < g.n; ++i)
             work += cdiv(g.p[i].m, bm) * cdiv(g.p[i].n, bn) * cdiv(g.p[i].k, BK);
-        static const long target = getenv("TFC_GEMM_TARGET_BLOCKS") ? atol(getenv("TFC_GEMM_TARGET_BLOCKS")) : 1536;
+        static const long target = getenv("TFC_GEMM_TARGET_BLOCKS") ? atol(getenv("TFC_GEMM_TARGET_BLOCKS")) : 1024;
         const long len = std::max<long>(8, cdiv(work, target));
         long used = 0;
         for (int i = 0; i < g.n; ++i) {
             Problem& p = g.p[i];
             const long nkt = cdiv(p.k, BK);
             const long mn = std::max<long>((long)p.m * p.n, 1);
-            long splits = std::min<long>(cdiv(nkt, len), max_splits(p.m, p.n, p.k));
+            // a range a little longer than `len` is cheaper than a second slab and a reduction pass
+            long splits = nkt * 2 > len * 3 ? std::min<long>(cdiv(nkt, len), max_splits(p.m, p.n, p.k)) : 1;
             splits = std::min<long>(splits, (workspace_floats - used) / mn);
             if (splits > 1) splits = cdiv(nkt, cdiv(nkt, splits));  // no empty range
             if (splits > 1) {

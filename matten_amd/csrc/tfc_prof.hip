@@ -34,7 +34,9 @@ int name_id(const char* name) {
 }  // namespace
 
 int tfc_prof_begin(const char* name, hipStream_t stream) {
-    if (!g_enabled.load(std::memory_order_relaxed)) return -1;
+    const int mode = g_enabled.load(std::memory_order_relaxed);
+    if (!mode) return -1;
+    if (mode == 2 && strncmp(name, "tfc_conv_", 9) != 0) return -1;  // convolution kernels only
     std::lock_guard<std::mutex> lk(g_mu);
     if (g_spans.size() >= MAX_SPANS) return -1;
     Span s;
@@ -62,7 +64,7 @@ void tfc_prof_end(int idx, hipStream_t stream) {
 }
 
 extern "C" int tfc_profile_enable(int on) {
-    g_enabled.store(on ? 1 : 0);
+    g_enabled.store(on == 2 ? 2 : (on ? 1 : 0));
     return TFC_OK;
 }
 

@@ -61,6 +61,9 @@ class ConvStack(torch.nn.Module):
         x = torch.nn.functional.one_hot(data["species_index"], w.shape[0]).to(w.dtype) @ w
         data[K.NODE_FEATURES] = x
         data[K.NODE_ATTRS] = x
+        # the attributes are an embedding of the species: tell the layers their classes (an
+        # extension the oracle's layers ignore)
+        data[K.NODE_ATTRS_CLASSES] = data["species_index"]
         data = self.spharm_edges(data)
         data = self.radial_basis(data)
         for layer in self.convs:

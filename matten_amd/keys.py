@@ -22,3 +22,9 @@ SPECIES_INDEX = "species_index"
 PER_ATOM_ENERGY = "atomic_energy"
 TOTAL_ENERGY = "total_energy"
 BATCH = "batch"
+
+# Extension (no counterpart in eigenn/data/_key.py): optional int64 [N] class index of the node
+# attributes, equal class => identical NODE_ATTRS row (for a species embedding: the species index).
+# When present the self connection takes its low-rank route without having to discover the classes
+# (which costs host synchronisations); when absent they are discovered from NODE_ATTRS itself.
+NODE_ATTRS_CLASSES = "node_attrs_classes"

@@ -133,10 +133,10 @@ class FullyConnectedTensorProduct(torch.nn.Module):
             a_covered=cov(self.irreps_in2, {b for _, b, _ in triples}),
         )
 
-    def forward(self, x, a, base: Optional[torch.Tensor] = None):
+    def forward(self, x, a, base: Optional[torch.Tensor] = None, classes: Optional[torch.Tensor] = None):
         if self._unsupported:
             raise NotImplementedError(f"matten_amd FullyConnectedTensorProduct: {self._unsupported}")
-        return ops.fctp(x, a, self.weight, self.spec, base)
+        return ops.fctp(x, a, self.weight, self.spec, base, classes=classes)
 
     def extra_repr(self):
         return f"{self.irreps_in1} x {self.irreps_in2} -> {self.irreps_out} | {self.weight_numel} weights"

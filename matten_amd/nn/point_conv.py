@@ -27,6 +27,7 @@ from .utils import ActivationLayer, UVUTensorProduct, scatter_add
 
 __all__ = ["PointConvMessage", "PointConvUpdate", "PointConvMessagePassing", "PointConv", "compile_mode"]
 
+_CLASSES = DataKey.NODE_ATTRS_CLASSES
 _NODE_MESSAGE = "_tfc_node_message"  # private hand-off: [N, D_mid] sums, already scaled
 
 
@@ -114,7 +115,7 @@ class PointConvUpdate(ModuleIrreps, torch.nn.Module):
         msg = self.linear_2(msg)
         if self.self_connection is not None:
             # out = msg + self_connection(x, attrs), accumulated into msg's buffer by the GEMM
-            node_feats = self.self_connection(node_feats, data[DataKey.NODE_ATTRS], base=msg)
+            node_feats = self.self_connection(node_feats, data[DataKey.NODE_ATTRS], base=msg, classes=data.get(_CLASSES))
         else:
             node_feats = msg
         data[DataKey.NODE_FEATURES] = node_feats
@@ -236,6 +237,6 @@ class PointConv(ModuleIrreps, torch.nn.Module):
         msg = self.tp(x, data[DataKey.EDGE_ATTRS], data[DataKey.EDGE_EMBEDDING], ordering=ordering, scale=scale)
         msg = self.linear_2(msg)
         if self.self_connection is not None:
-            msg = self.self_connection(x_in, data[DataKey.NODE_ATTRS], base=msg)
+            msg = self.self_connection(x_in, data[DataKey.NODE_ATTRS], base=msg, classes=data.get(_CLASSES))
         data[DataKey.NODE_FEATURES] = msg
         return data

@@ -39,7 +39,7 @@ __all__ = [
 
 
 def _stream():
-    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    return C.c_void_p(torch._C._cuda_getCurrentRawStream(torch.cuda.current_device()))
 
 
 def _ptr(t: Optional[torch.Tensor], offset: int = 0):
@@ -793,38 +793,80 @@ def _fctp_dw(n, x, a, d_a, gt, dw, spec, ins_list):
 
 
 _ATTR_FACTORS: "dict[tuple, tuple]" = {}
+_ATTR_CLASSES: "dict[tuple, tuple]" = {}
+_HASH_COEF: "dict[tuple, torch.Tensor]" = {}
 
 
-def attr_factors(a: torch.Tensor):
+def _class_structure(labels: torch.Tensor):
+    """(inv [N] dense class ids, rep [u] first row of each class, one-hot C [N, r], u, r) of an
+    integer labelling; one host sync (the number of classes)."""
+    n = labels.shape[0]
+    uniq, inv = torch.unique(labels, return_inverse=True)  # sync
+    u = int(uniq.numel())
+    r = max(4, (u + 3) // 4 * 4)
+    ar = torch.arange(n, device=labels.device)
+    rep = torch.full((u,), n, dtype=torch.int64, device=labels.device)
+    rep.scatter_reduce_(0, inv, ar, reduce="amin")
+    Cm = torch.zeros(n, r, dtype=torch.float32, device=labels.device)
+    Cm[ar, inv] = 1.0
+    return inv, rep, Cm, u, r
+
+
+def attr_factors(a: torch.Tensor, classes: Optional[torch.Tensor] = None):
     """(C [N, r], R [r, d_a]) with a == C @ R exactly, when the rows of `a` are copies of a few distinct
     rows (node attributes that are a species embedding: eigenn/nn/embedding.py:59-75 sets NODE_ATTRS
     to embedding(species), so at most n_species distinct rows) - else None.  C is the one-hot matrix
-    of the row classes, R the distinct rows (zero padded to r, a multiple of 4).  Costs two host
-    syncs, paid once per tensor: the result is cached on (address, version) with the tensor held
-    alive, so the layers of a model, forward and backward, share it."""
-    key = (a.data_ptr(), a._version, tuple(a.shape))
-    hit = _ATTR_FACTORS.get(key)
-    if hit is not None:
-        return hit[1]
+    of the row classes, R the distinct rows (zero padded to r, a multiple of 4).
+
+    `classes` (keys.NODE_ATTRS_CLASSES): int64 [N], equal class => identical row, supplied by the
+    caller and trusted; the class structure is then cached per `classes` tensor and a call costs
+    one row gather.  Without it the classes are discovered from the bit patterns of `a` and
+    verified (two host syncs), once per tensor: the result is cached on (address, version) with
+    the tensor held alive, so the layers of a model, forward and backward, share it."""
     n, d_a = a.shape
-    res = None
-    if n >= 64 and d_a >= 8 and a.is_contiguous():
+    if n < 64 or d_a < 8 or not a.is_contiguous():
+        return None
+    if classes is not None:
+        ckey = (classes.data_ptr(), classes._version, n)
+        hit = _ATTR_CLASSES.get(ckey)
+        if hit is None:
+            with torch.no_grad():
+                st = _class_structure(classes.reshape(-1).to(torch.int64))
+            if len(_ATTR_CLASSES) >= 8:
+                _ATTR_CLASSES.pop(next(iter(_ATTR_CLASSES)))
+            hit = (classes, st)
+            _ATTR_CLASSES[ckey] = hit
+        inv, rep, Cm, u, r = hit[1]
+        if 2 * r > d_a:
+            return None
+        key = (a.data_ptr(), a._version, tuple(a.shape), ckey)
+        fhit = _ATTR_FACTORS.get(key)
+        if fhit is not None:
+            return fhit[1]
         with torch.no_grad():
-            gen = torch.Generator().manual_seed(0x5EED)
-            coef = (torch.randint(1, 1 << 40, (d_a,), generator=gen, dtype=torch.int64) * 2 + 1).to(a.device)
+            R = torch.zeros(r, d_a, dtype=torch.float32, device=a.device)
+            R[:u] = a.detach()[rep]
+        res = (Cm, R)
+    else:
+        key = (a.data_ptr(), a._version, tuple(a.shape), None)
+        fhit = _ATTR_FACTORS.get(key)
+        if fhit is not None:
+            return fhit[1]
+        res = None
+        with torch.no_grad():
+            ck = (a.device, d_a)
+            coef = _HASH_COEF.get(ck)
+            if coef is None:
+                gen = torch.Generator().manual_seed(0x5EED)
+                coef = (torch.randint(1, 1 << 40, (d_a,), generator=gen, dtype=torch.int64) * 2 + 1).to(a.device)
+                _HASH_COEF[ck] = coef
             h = (a.detach().view(torch.int32).to(torch.int64) * coef).sum(dim=1)
-            uniq, inv = torch.unique(h, return_inverse=True)  # sync
-            u = int(uniq.numel())
-            r = max(4, (u + 3) // 4 * 4)
+            inv, rep, Cm, u, r = _class_structure(h)
             if 2 * r <= d_a:
-                rep = torch.full((u,), n, dtype=torch.int64, device=a.device)
-                rep.scatter_reduce_(0, inv, torch.arange(n, device=a.device), reduce="amin")
                 rows = a.detach()[rep]
                 if bool((rows[inv] == a.detach()).all().item()):  # sync; also rejects NaN rows
                     R = torch.zeros(r, d_a, dtype=torch.float32, device=a.device)
                     R[:u] = rows
-                    Cm = torch.zeros(n, r, dtype=torch.float32, device=a.device)
-                    Cm[torch.arange(n, device=a.device), inv] = 1.0
                     res = (Cm, R)
     if len(_ATTR_FACTORS) >= 8:
         _ATTR_FACTORS.pop(next(iter(_ATTR_FACTORS)))
@@ -927,11 +969,12 @@ class _FctpFn(torch.autograd.Function):
         return dx, da, dw, None, (g if ctx.has_base else None), None
 
 
-def fctp(x, a, weight, spec: FctpSpec, base: Optional[torch.Tensor] = None, low_rank: bool = True):
+def fctp(x, a, weight, spec: FctpSpec, base: Optional[torch.Tensor] = None, low_rank: bool = True,
+         classes: Optional[torch.Tensor] = None):
     """FullyConnectedTensorProduct(x, a) with scalar `a`; when `base` is given the result is
     accumulated into it in place (out = base + fctp), saving the separate add.  `low_rank`: take the
     shorter contraction when the rows of `a` are copies of a few distinct rows (attr_factors)."""
-    factors = attr_factors(a) if low_rank else None
+    factors = attr_factors(a, classes) if low_rank else None
     return _FctpFn.apply(x, a, weight, spec, base, factors)
 
 
