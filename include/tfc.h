@@ -209,6 +209,7 @@ int tfc_edge_vec_bwd(const float* dvec, const int32_t* rp_src, const int32_t* ei
  * FullyConnectedTensorProduct self connection (:159-164,185-188), forward and backward:
  *
  *   C[addrC(r,j)] (+)= epilogue( alpha * sum_k A1[addrA1(r,k)] * (A2 ? A2[addrA2(r,k)] : 1) * B[addrB(k,j)] )
+ *   (see a_rep below for an A element that is itself a short sum of such products)
  *
  * Every address is a sum of per-index maps  f(t) = (t / (d1*d2))*s0 + ((t / d2) % d1)*s1 + (t % d2)*s2,
  * which is what lets one kernel walk e3nn's [node][mul][2l+1] blocks without materialising
@@ -234,6 +235,13 @@ typedef struct tfc_gemm_desc {
     float* workspace;   /* optional scratch for split-K (small m x n, long k); null: never split */
     int64_t workspace_floats;
     const char* tag;    /* optional name under which tfc_profile_report() books this call */
+    /* a_rep > 1 (two factors only): the A element is
+     *     sum_{m < a_rep} A1[a1R(r)+a1K(k)+m*a1_rep_stride] * A2[a2R(r)+a2K(k)+m*a2_rep_stride],
+     * i.e. a short contraction (the 2l+1 components of an irrep) folded into the operand instead of
+     * lengthening K.  Supported for a_rep in {3,5,7} when both factors can be staged in 16-byte
+     * groups along k (TFC_EUNSUPPORTED otherwise; 0 or 1: no repetition). */
+    int32_t a_rep;
+    int64_t a1_rep_stride, a2_rep_stride;
 } tfc_gemm_desc;
 
 #define TFC_EPI_NONE 0

@@ -61,6 +61,9 @@ class GemmDesc(C.Structure):
         ("workspace", C.c_void_p),
         ("workspace_floats", C.c_int64),
         ("tag", C.c_char_p),
+        ("a_rep", C.c_int32),
+        ("a1_rep_stride", C.c_int64),
+        ("a2_rep_stride", C.c_int64),
     ]
 
 

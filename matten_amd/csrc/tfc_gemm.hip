@@ -52,6 +52,8 @@ struct Problem {
     int splits;       // > 1: K is cut into `splits` ranges
     int block_begin;  // first virtual block of this problem in the launch
     int accumulate, epilogue;
+    int a_rep;         // A element = sum over a_rep repetitions of the two factors, strides below
+    long a1_rs, a2_rs;
     float alpha, act_cst;
 };
 
@@ -90,7 +92,7 @@ __device__ __forceinline__ float epilogue_apply(const Problem& P, float acc, lon
 // load() only ISSUES the global loads; the product of the two factors and the zeroing of the K
 // tail happen in store(), after the MFMAs of the current tile, so that nothing waits on the loads
 // while they are in flight.
-template <int BX, bool KFAST, bool HAS2, bool VEC>
+template <int BX, bool KFAST, bool HAS2, bool VEC, int REP = 1>
 struct Operand {
     static constexpr int NE = BX * BK / 256;  // elements per thread
     static constexpr int S = BX + 4;          // LDS row stride
@@ -98,7 +100,8 @@ struct Operand {
 
     __device__ __forceinline__ void load(const float* __restrict__ p, const float* __restrict__ p2,
                                          const long* __restrict__ roff, const long* __restrict__ roff2,
-                                         const long* __restrict__ ko, const long* __restrict__ ko2, int t) {
+                                         const long* __restrict__ ko, const long* __restrict__ ko2, int t, long,
+                                         long) {
         if (KFAST) {
             const int kk = t % BK;
             const long o = ko[kk];
@@ -147,16 +150,20 @@ struct Operand {
 // v of the self connection) and the SECOND contiguous; the host swaps the factors into that order
 // and selects this variant only when the maps, the base pointers and the extents guarantee
 // aligned, in-bounds groups (flags_of()).
-template <int BX, bool KFAST, bool HAS2>
-struct Operand<BX, KFAST, HAS2, true> {
+template <int BX, bool KFAST, bool HAS2, int REP>
+struct Operand<BX, KFAST, HAS2, true, REP> {
     static constexpr int NV = BX * BK / 1024;  // groups per thread
     static constexpr int S = BX + 4;
-    float4 v[NV];
-    float s[HAS2 ? NV : 1];
+    float4 v[NV][REP];
+    float s[HAS2 ? NV : 1][REP];
 
+    // REP > 1 (two factors only): the element is sum_{m < REP} f1(. + m rs1) * f2(. + m rs2), summed
+    // at store time - a contraction index that is too short for the matrix cores (the 2l+1
+    // components of an irrep) folded into the staging instead of lengthening K by 2l+1
     __device__ __forceinline__ void load(const float* __restrict__ p, const float* __restrict__ p2,
                                          const long* __restrict__ roff, const long* __restrict__ roff2,
-                                         const long* __restrict__ ko, const long* __restrict__ ko2, int t) {
+                                         const long* __restrict__ ko, const long* __restrict__ ko2, int t,
+                                         long rs1, long rs2) {
         // (p, roff, ko) address the broadcast factor when HAS2, the only factor otherwise
         if (KFAST) {
             const int kq = t & 3;  // k = 4 kq .. 4 kq + 3
@@ -166,10 +173,15 @@ struct Operand<BX, KFAST, HAS2, true> {
             for (int q = 0; q < NV; ++q) {
                 const int x = (t >> 2) + 64 * q;
                 if (HAS2) {
-                    s[q] = p[roff[x] + o];
-                    v[q] = *reinterpret_cast<const float4*>(p2 + roff2[x] + o2);
+                    const float* b1 = p + roff[x] + o;
+                    const float* b2 = p2 + roff2[x] + o2;
+#pragma unroll
+                    for (int m = 0; m < REP; ++m) {
+                        s[q][m] = b1[m * rs1];
+                        v[q][m] = *reinterpret_cast<const float4*>(b2 + m * rs2);
+                    }
                 } else {
-                    v[q] = *reinterpret_cast<const float4*>(p + roff[x] + o);
+                    v[q][0] = *reinterpret_cast<const float4*>(p + roff[x] + o);
                 }
             }
         } else {
@@ -180,10 +192,15 @@ struct Operand<BX, KFAST, HAS2, true> {
             for (int q = 0; q < NV; ++q) {
                 const int kk = t / (BX / 4) + (1024 / BX) * q;
                 if (HAS2) {
-                    s[q] = p[r + ko[kk]];
-                    v[q] = *reinterpret_cast<const float4*>(p2 + r2 + ko2[kk]);
+                    const float* b1 = p + r + ko[kk];
+                    const float* b2 = p2 + r2 + ko2[kk];
+#pragma unroll
+                    for (int m = 0; m < REP; ++m) {
+                        s[q][m] = b1[m * rs1];
+                        v[q][m] = *reinterpret_cast<const float4*>(b2 + m * rs2);
+                    }
                 } else {
-                    v[q] = *reinterpret_cast<const float4*>(p + r + ko[kk]);
+                    v[q][0] = *reinterpret_cast<const float4*>(p + r + ko[kk]);
                 }
             }
         }
@@ -192,12 +209,19 @@ struct Operand<BX, KFAST, HAS2, true> {
     __device__ __forceinline__ void store(float* __restrict__ lds, int t, int k_left) const {
 #pragma unroll
         for (int q = 0; q < NV; ++q) {
-            float4 a = v[q];
+            float4 a = v[q][0];
             if (HAS2) {
-                a.x *= s[q];
-                a.y *= s[q];
-                a.z *= s[q];
-                a.w *= s[q];
+                a.x *= s[q][0];
+                a.y *= s[q][0];
+                a.z *= s[q][0];
+                a.w *= s[q][0];
+#pragma unroll
+                for (int m = 1; m < REP; ++m) {
+                    a.x = fmaf(s[q][m], v[q][m].x, a.x);
+                    a.y = fmaf(s[q][m], v[q][m].y, a.y);
+                    a.z = fmaf(s[q][m], v[q][m].z, a.z);
+                    a.w = fmaf(s[q][m], v[q][m].w, a.w);
+                }
             }
             if (KFAST) {
                 const int k = 4 * (t & 3), x = (t >> 2) + 64 * q;
@@ -220,7 +244,7 @@ struct Operand<BX, KFAST, HAS2, true> {
     }
 };
 
-template <int TM, int TN, bool A_KFAST, bool B_KFAST, bool HAS2, bool AV, bool BV>
+template <int TM, int TN, int REP, bool A_KFAST, bool B_KFAST, bool HAS2, bool AV, bool BV>
 __global__ __launch_bounds__(256, (TM * TN == 4 ? 4 : 1)) void tfc_gemm_kernel(const Group g) {
     constexpr int BM = 64 * TM, BN = 64 * TN, SA = BM + 4, SB = BN + 4;
     constexpr int TILE = BK * SA + BK * SB;
@@ -299,11 +323,12 @@ __global__ __launch_bounds__(256, (TM * TN == 4 ? 4 : 1)) void tfc_gemm_kernel(c
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    Operand<BM, A_KFAST, HAS2, AV> A;
-    Operand<BN, B_KFAST, false, BV> B;
+    Operand<BM, A_KFAST, HAS2, AV, REP> A;
+    Operand<BN, B_KFAST, false, BV, 1> B;
+    const long rs1 = P.a1_rs, rs2 = P.a2_rs;
     if (n_tiles > 0) {
-        A.load(pa1, pa2, roffA, roffA2, koff[0][0], koff[0][1], t);
-        B.load(pb, nullptr, roffB, nullptr, koff[0][2], nullptr, t);
+        A.load(pa1, pa2, roffA, roffA2, koff[0][0], koff[0][1], t, rs1, rs2);
+        B.load(pb, nullptr, roffB, nullptr, koff[0][2], nullptr, t, 0, 0);
         A.store(tiles, t, K - kt_begin * BK);
         B.store(tiles + BK * SA, t, K - kt_begin * BK);
     }
@@ -333,8 +358,8 @@ __global__ __launch_bounds__(256, (TM * TN == 4 ? 4 : 1)) void tfc_gemm_kernel(c
         const int cur = i & 1, nxt = cur ^ 1;
         {
             const int kb_ = ((i + 1) / KT) & 1, ko_ = ((i + 1) % KT) * BK;
-            A.load(pa1, pa2, roffA, roffA2, koff[kb_][0] + ko_, koff[kb_][1] + ko_, t);
-            B.load(pb, nullptr, roffB, nullptr, koff[kb_][2] + ko_, nullptr, t);
+            A.load(pa1, pa2, roffA, roffA2, koff[kb_][0] + ko_, koff[kb_][1] + ko_, t, rs1, rs2);
+            B.load(pb, nullptr, roffB, nullptr, koff[kb_][2] + ko_, nullptr, t, 0, 0);
         }
         mfma_tile(cur);
         // the offsets of tiles i + KT .. replace those of tiles i - KT .. i - 1 (last read before
@@ -470,8 +495,10 @@ bool factor_vec_ok(const float* p, const tfc_imap& fast, long n_fast, const tfc_
 
 struct Flags {
     bool a_kfast, b_kfast, has2, av, bv;
+    int rep;
     bool operator==(const Flags& o) const {
-        return a_kfast == o.a_kfast && b_kfast == o.b_kfast && has2 == o.has2 && av == o.av && bv == o.bv;
+        return a_kfast == o.a_kfast && b_kfast == o.b_kfast && has2 == o.has2 && av == o.av && bv == o.bv &&
+               rep == o.rep;
     }
 };
 
@@ -483,6 +510,7 @@ struct Flags {
 Flags flags_of(const tfc_gemm_desc& d, bool* swap12) {
     Flags f;
     f.has2 = d.a2 != nullptr;
+    f.rep = d.a_rep > 1 ? d.a_rep : 1;
     int cost[2];
     bool vec[2], swp[2] = {false, false};
     for (int kf = 0; kf < 2; ++kf) {
@@ -548,6 +576,9 @@ int convert(const tfc_gemm_desc* d, Problem* p) {
     p->act_cst = d->act_cst;
     p->accumulate = d->accumulate;
     p->epilogue = d->epilogue;
+    p->a_rep = d->a_rep > 1 ? d->a_rep : 1;
+    p->a1_rs = d->a1_rep_stride;
+    p->a2_rs = d->a2_rep_stride;
     int rc;
     if ((rc = convert_map(d->a1_r, &p->a1_r, "a1_r"))) return rc;
     if ((rc = convert_map(d->a1_k, &p->a1_k, "a1_k"))) return rc;
@@ -569,7 +600,18 @@ inline long cdiv(long a, long b) { return (a + b - 1) / b; }
 
 template <int TM, int TN, bool... B>
 void dispatch(const Group& g, dim3 grid, hipStream_t stream) {
-    tfc_gemm_kernel<TM, TN, B...><<<grid, dim3(256), 0, stream>>>(g);
+    tfc_gemm_kernel<TM, TN, 1, B...><<<grid, dim3(256), 0, stream>>>(g);
+}
+// repeated two-factor operand (a_rep = 3, 5, 7): 64 x 64 tile, A walked along k in 16-byte groups
+template <int REP>
+void dispatch_rep(const Group& g, dim3 grid, hipStream_t stream, bool b_kfast, bool bv) {
+    if (b_kfast) {
+        if (bv) tfc_gemm_kernel<1, 1, REP, true, true, true, true, true><<<grid, dim3(256), 0, stream>>>(g);
+        else tfc_gemm_kernel<1, 1, REP, true, true, true, true, false><<<grid, dim3(256), 0, stream>>>(g);
+    } else {
+        if (bv) tfc_gemm_kernel<1, 1, REP, true, false, true, true, true><<<grid, dim3(256), 0, stream>>>(g);
+        else tfc_gemm_kernel<1, 1, REP, true, false, true, true, false><<<grid, dim3(256), 0, stream>>>(g);
+    }
 }
 template <int TM, int TN, bool... B, typename... Rest>
 void dispatch(const Group& g, dim3 grid, hipStream_t stream, bool first, Rest... rest) {
@@ -592,7 +634,10 @@ int launch_tile(Group& g, const Flags& f, const char* tag, hipStream_t stream) {
     }
     const dim3 grid((unsigned)nb), block(256);
     TfcProfScope prof(tag, stream);
-    dispatch<TM, TN>(g, grid, stream, f.a_kfast, f.b_kfast, f.has2, f.av, f.bv);
+    if (f.rep == 1) dispatch<TM, TN>(g, grid, stream, f.a_kfast, f.b_kfast, f.has2, f.av, f.bv);
+    else if (f.rep == 3) dispatch_rep<3>(g, grid, stream, f.b_kfast, f.bv);
+    else if (f.rep == 5) dispatch_rep<5>(g, grid, stream, f.b_kfast, f.bv);
+    else dispatch_rep<7>(g, grid, stream, f.b_kfast, f.bv);
     TFC_LAUNCH_CHECK("tfc_gemm_kernel");
     if (any_split) {
         long big = 1;
@@ -631,7 +676,7 @@ int launch_group(Group& g, const Flags& f, float* workspace, long workspace_floa
         }
     }
     int pick = 2;
-    for (int c = 1; c >= 0; --c)
+    for (int c = 1; c >= 0 && f.rep == 1; --c)  // the repeated-factor staging exists for the 64 x 64 tile only
         if (blocks[c] >= 256 && padded[c] * 100 <= padded[2] * 112) pick = c;
     const int bm = cand[pick][0], bn = cand[pick][1];
     // K ranges.  All blocks of a launch should carry a similar number of K tiles (the problems of
@@ -687,6 +732,14 @@ extern "C" int tfc_gemm_group(const tfc_gemm_desc* descs, int32_t n_descs, tfc_s
         }
         bool swap12 = false;
         const Flags f = flags_of(descs[first], &swap12);
+        if (f.rep > 1) {
+            const tfc_gemm_desc& d0 = descs[first];
+            TFC_REQUIRE((f.rep == 3 || f.rep == 5 || f.rep == 7) && f.has2 && f.av && f.a_kfast, TFC_EUNSUPPORTED,
+                        "tfc_gemm: a_rep=%d needs two factors that can be staged in 16-byte groups along k "
+                        "(one constant, one contiguous over each group) and a_rep in {3,5,7}", f.rep);
+            TFC_REQUIRE((swap12 ? d0.a1_rep_stride : d0.a2_rep_stride) % 4 == 0, TFC_EUNSUPPORTED,
+                        "tfc_gemm: repetition stride of the contiguous factor must be a multiple of 4");
+        }
         Group g;
         g.n = 0;
         float* ws = nullptr;
@@ -700,6 +753,7 @@ extern "C" int tfc_gemm_group(const tfc_gemm_desc* descs, int32_t n_descs, tfc_s
                 std::swap(g.p[g.n].a1, g.p[g.n].a2);
                 std::swap(g.p[g.n].a1_r, g.p[g.n].a2_r);
                 std::swap(g.p[g.n].a1_k, g.p[g.n].a2_k);
+                std::swap(g.p[g.n].a1_rs, g.p[g.n].a2_rs);
             }
             if (descs[i].workspace && descs[i].workspace_floats > ws_floats) {
                 ws = descs[i].workspace;

@@ -9,6 +9,7 @@ SURVEY.md §3.3).  There is no CPU / eager fallback: tensors must live on a ROCm
 from __future__ import annotations
 
 import ctypes as C
+import functools
 import math
 import weakref
 from dataclasses import dataclass
@@ -458,12 +459,19 @@ def radial_embedding(vec, length, bessel_weights, r_max: float, p: float = 6.0):
 # ======================================================================================
 
 
+@functools.lru_cache(maxsize=4096)
 def _imap(d1=1, d2=1, s0=0, s1=0, s2=0) -> IMap:
+    """(cached: the maps are read-only once built, and a step builds thousands of them)"""
     return IMap(int(d1), int(d2), int(s0), int(s1), int(s2))
 
 
 def _lin(stride) -> IMap:  # f(t) = t * stride
     return _imap(1, 1, stride, 0, 0)
+
+
+@functools.lru_cache(maxsize=4096)
+def _ws_floats(m: int, n: int, k: int) -> int:
+    return int(_lib.lib().tfc_gemm_workspace_floats(m, n, k))
 
 
 _GEMM_WS: "dict[int, torch.Tensor]" = {}
@@ -480,8 +488,9 @@ def _gemm_workspace(n_floats: int) -> torch.Tensor:
 
 
 def _desc(m, n, k, a1, b, c, a1_r, a1_k, b_k, b_j, c_r, c_j, alpha=1.0, accumulate=False, a2=None, a2_r=None, a2_k=None,
-          epilogue=_lib.EPI_NONE, aux=None, act_cst=1.0, tag=None) -> GemmDesc:
+          epilogue=_lib.EPI_NONE, aux=None, act_cst=1.0, tag=None, a_rep=1, a1_rs=0, a2_rs=0) -> GemmDesc:
     d = GemmDesc()
+    d.a_rep, d.a1_rep_stride, d.a2_rep_stride = int(a_rep), int(a1_rs), int(a2_rs)
     d.tag = tag
     d.m, d.n, d.k = int(m), int(n), int(k)
     d.a1, d.b, d.c = a1, b, c
@@ -508,7 +517,7 @@ def _gemm_group(descs: "List[GemmDesc]"):
     if not descs:
         return
     L = _lib.lib()
-    need = sum(int(L.tfc_gemm_workspace_floats(d.m, d.n, d.k)) for d in descs)
+    need = sum(_ws_floats(d.m, d.n, d.k) for d in descs)
     arr = (GemmDesc * len(descs))(*descs)
     if need > 0:
         ws = _gemm_workspace(need)
@@ -757,6 +766,12 @@ def _fctp_dx(n, a, d_a, weight, gt, dx, spec, ins_list):
     _gemm_waves([(ins[0], bdx(*ins)) for ins in ins_list])
 
 
+import os as _os
+
+# irrep dimensions whose component sum is folded into the operand of the da product (a_rep)
+_FOLD_DIMS = tuple(int(v) for v in _os.environ.get("TFC_FOLD_DIMS", "3,5").split(",") if v)
+
+
 def _fctp_da(n, xt, weight, gt, spec, ins_list, d_a, a_covered):
     """da[n, v] = alpha sum_{(k,u,w)} x[n,u,k] g[n,w,k] W[u,v,w].  Every instruction adds to the same
     block of `da`: each writes its own partial [N, mul_v] in one grouped launch, and the partials
@@ -765,16 +780,28 @@ def _fctp_da(n, xt, weight, gt, spec, ins_list, d_a, a_covered):
     part = torch.empty(ni, n, d_a, dtype=torch.float32, device=xt.device)
     if not a_covered or any(ins[3] != d_a for ins in ins_list):
         part.zero_()
-    _gemm_group([
-        _desc(
-            n, mv, d * mu * mw, _p(xt, xo * n), _p(weight, wo), _p(part, i * n * d_a + ao),
-            a1_r=_lin(mu), a1_k=_imap(mu, mw, n * mu, 1, 0),
-            a2=_p(gt, oo * n), a2_r=_lin(mw), a2_k=_imap(mu, mw, n * mw, 0, 1),
-            b_k=_imap(mu, mw, 0, mv * mw, 1), b_j=_lin(mw), c_r=_lin(d_a), c_j=_lin(1), alpha=alpha,
-            tag=b"gemm_fctp_da",
-        )
-        for i, (xo, mu, ao, mv, oo, mw, d, wo, alpha) in enumerate(ins_list)
-    ])
+    descs = []
+    for i, (xo, mu, ao, mv, oo, mw, d, wo, alpha) in enumerate(ins_list):
+        # (pays while the product has few columns: measured faster at mul_v = 64, slower at 128)
+        fold = d in _FOLD_DIMS and mv <= 64 and mw % 4 == 0 and (oo * n) % 4 == 0 and (n * mw) % 4 == 0 and gt.data_ptr() % 16 == 0
+        if fold:
+            # the sum over the 2l+1 components k is folded into the operand (a_rep): K = mu * mw
+            descs.append(_desc(
+                n, mv, mu * mw, _p(xt, xo * n), _p(weight, wo), _p(part, i * n * d_a + ao),
+                a1_r=_lin(mu), a1_k=_imap(1, mw, 1, 0, 0),
+                a2=_p(gt, oo * n), a2_r=_lin(mw), a2_k=_imap(1, mw, 0, 0, 1),
+                b_k=_imap(1, mw, mv * mw, 0, 1), b_j=_lin(mw), c_r=_lin(d_a), c_j=_lin(1), alpha=alpha,
+                tag=b"gemm_fctp_da", a_rep=d, a1_rs=n * mu, a2_rs=n * mw,
+            ))
+        else:
+            descs.append(_desc(
+                n, mv, d * mu * mw, _p(xt, xo * n), _p(weight, wo), _p(part, i * n * d_a + ao),
+                a1_r=_lin(mu), a1_k=_imap(mu, mw, n * mu, 1, 0),
+                a2=_p(gt, oo * n), a2_r=_lin(mw), a2_k=_imap(mu, mw, n * mw, 0, 1),
+                b_k=_imap(mu, mw, 0, mv * mw, 1), b_j=_lin(mw), c_r=_lin(d_a), c_j=_lin(1), alpha=alpha,
+                tag=b"gemm_fctp_da",
+            ))
+    _gemm_group(descs)
     return part.sum(dim=0) if ni > 1 else part[0]
 
 

@@ -51,7 +51,7 @@ def main():
                 torch.autograd.grad(o, [x, w] + ([yy] if need_dy else []), g)
             r = timeit(step)
             f, b = r["tfc_conv_fwd_kernel"], r["tfc_conv_bwd_kernel"]
-            print(f"L{li} d_in={d_in} d_mid={d_mid} W={W} dy={need_dy}: fwd {f:7.1f} us {b_fwd/f/1e3:7.0f} GB/s | bwd {b:7.1f} us {b_bwd/b/1e3:7.0f} GB/s | prepass {r['tfc_m_prepass_kernel']:6.1f} us")
+            print(f"L{li} d_in={d_in} d_mid={d_mid} W={W} dy={need_dy}: fwd {f:7.1f} us {b_fwd/f/1e3:7.0f} GB/s | bwd {b:7.1f} us {b_bwd/b/1e3:7.0f} GB/s | prepass {r.get('tfc_m_prepass_kernel', 0.0):6.1f} us")
 
 if __name__ == "__main__":
     main()

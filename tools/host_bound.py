@@ -24,8 +24,13 @@ t1 = time.perf_counter()
 torch.cuda.synchronize()
 t2 = time.perf_counter()
 print(f"enqueue {1e3*(t1-t0)/20:.3f} ms/step, total {1e3*(t2-t0)/20:.3f} ms/step")
+one = []
+for _ in range(10):
+    torch.cuda.synchronize(); ta = time.perf_counter(); step(); tb = time.perf_counter(); one.append(tb - ta)
+torch.cuda.synchronize()
+print(f"host time of one step issued into an empty queue: median {1e3*sorted(one)[5]:.3f} ms")
 import cProfile, pstats
 pr = cProfile.Profile(); pr.enable()
 for _ in range(10): step()
 pr.disable(); torch.cuda.synchronize()
-pstats.Stats(pr).sort_stats("cumulative").print_stats(35)
+pstats.Stats(pr).sort_stats("tottime").print_stats(40)
