@@ -52,6 +52,7 @@ class ConvStack(torch.nn.Module):
         self.d_out = Irreps(str(cur[K.NODE_FEATURES])).dim
         g = torch.Generator().manual_seed(7)
         self.register_buffer("readout", torch.randn(self.d_out, generator=g) / self.d_out**0.5)
+        self.classes_hint = True  # False: the layers find the row classes of the attributes themselves
 
     def forward(self, batch, n_graphs: int):
         data = dict(batch)
@@ -63,7 +64,8 @@ class ConvStack(torch.nn.Module):
         data[K.NODE_ATTRS] = x
         # the attributes are an embedding of the species: tell the layers their classes (an
         # extension the oracle's layers ignore)
-        data[K.NODE_ATTRS_CLASSES] = data["species_index"]
+        if self.classes_hint:
+            data[K.NODE_ATTRS_CLASSES] = data["species_index"]
         data = self.spharm_edges(data)
         data = self.radial_basis(data)
         for layer in self.convs:

@@ -819,6 +819,7 @@ def _fctp_dw(n, x, a, d_a, gt, dw, spec, ins_list):
     ])
 
 
+ROUTE_COUNTS = {"fctp_dense": 0, "fctp_low_rank": 0}  # forward calls per self-connection route (read by tests)
 _ATTR_FACTORS: "dict[tuple, tuple]" = {}
 _ATTR_CLASSES: "dict[tuple, tuple]" = {}
 _HASH_COEF: "dict[tuple, torch.Tensor]" = {}
@@ -926,6 +927,7 @@ class _FctpFn(torch.autograd.Function):
             alloc = torch.empty if spec.out_covered else torch.zeros
             out = alloc(n, spec.d_out, dtype=torch.float32, device=x.device)
             on_base = False
+        ROUTE_COUNTS["fctp_dense" if factors is None else "fctp_low_rank"] += 1
         if factors is None:
             _fctp_fwd(n, x, a, spec.d_a, weight, out, spec, spec.instructions, on_base)
             ctx.save_for_backward(x, a, weight)

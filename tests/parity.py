@@ -31,6 +31,11 @@ CONFIGS = {
     "minimal": dict(emb=32, lmax=2, irreps="32x0o+32x0e+16x1o+16x1e+8x2o+8x2e", layers=3, hidden=64, nh=2, n=2, a=2.55, graphs=3),
     "lmax3": dict(emb=16, lmax=3, irreps="16x0o+16x0e+16x1o+16x1e+8x2o+8x2e+4x3o+4x3e", layers=3, hidden=32, nh=1, n=2, a=2.7, graphs=2),
     "c3": dict(emb=64, lmax=2, irreps="64x0o+64x0e+64x1o+64x1e+64x2o+64x2e", layers=3, hidden=64, nh=2, n=3, a=2.5, graphs=2),
+    # >= 64 nodes: the self connection takes its low-rank route (matten_amd/ops.py attr_factors), with the
+    # species classes handed over ("c3_lowrank") or found from the attribute rows ("c3_lowrank_nohint")
+    "c3_lowrank": dict(emb=64, lmax=2, irreps="64x0o+64x0e+64x1o+64x1e+64x2o+64x2e", layers=2, hidden=64, nh=2, n=3, a=2.5, graphs=3),
+    "c3_lowrank_nohint": dict(emb=64, lmax=2, irreps="64x0o+64x0e+32x1o+32x1e+16x2o+16x2e", layers=2, hidden=64, nh=2, n=3, a=2.5,
+                              graphs=3, hint=False),
     "c4": dict(emb=128, lmax=3, irreps="128x0o+128x0e+128x1o+128x1e+128x2o+128x2e+128x3o+128x3e", layers=2, hidden=64, nh=2, n=2, a=2.6, graphs=1),
 }
 R_CUT = 5.0
@@ -52,7 +57,9 @@ def Stack(impl, cfg):
         from oracle import eigenn_ref as M
     else:
         import matten_amd.nn as M
-    return ConvStack(M, cfg["emb"], cfg["lmax"], cfg["irreps"], cfg["layers"], cfg["hidden"], cfg["nh"], R_CUT, AVG_NEIGH)
+    stack = ConvStack(M, cfg["emb"], cfg["lmax"], cfg["irreps"], cfg["layers"], cfg["hidden"], cfg["nh"], R_CUT, AVG_NEIGH)
+    stack.classes_hint = cfg.get("hint", True)
+    return stack
 
 
 def _prep(batch, device, dtype):

@@ -9,9 +9,14 @@ from tests.parity import CONFIGS, run_layer_parity
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("config", ["smoke", "minimal", "lmax3", "c3", "c4"])
+@pytest.mark.parametrize("config", ["smoke", "minimal", "lmax3", "c3", "c3_lowrank", "c3_lowrank_nohint", "c4"])
 def test_stack_parity(device, config):
+    from matten_amd import ops
+
+    before = dict(ops.ROUTE_COUNTS)
     out = run_layer_parity(config, device=str(device), verbose=True)
+    took_low_rank = ops.ROUTE_COUNTS["fctp_low_rank"] > before["fctp_low_rank"]
+    assert took_low_rank == config.startswith("c3_lowrank"), "self connection took an unexpected route"
     bad = {k: v for k, v in out["report"].items() if v[0] > out["tol"]}
     assert out["ok"], f"worst {out['worst']:.2e} > {out['tol']:.0e}: {bad}"
 

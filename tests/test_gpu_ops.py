@@ -380,3 +380,235 @@ def test_c_abi_rejects_bad_arguments(device):
     rc = L.tfc_conv_plan_create(bad, 1, 44, 1, 44, 4, C.byref(out))
     assert rc == -1
     assert L.tfc_conv_fwd(None, None, None, None, None, None, None, 1, 1, 1.0, None, None, None) == -1
+
+
+# --------------------------------------------------------------------------------------- newer entry points
+def test_conv_one_call_entry_points_match_m_route(device):
+    """tfc_conv_fwd / tfc_conv_bwd (M built inside, workspace argument) against the tfc_conv_m_build +
+    tfc_conv_fwd_m / tfc_conv_bwd_m route the modules take: same kernels, so bit-identical."""
+    import ctypes as C
+
+    from matten_amd import _lib, ops
+    from matten_amd.nn.utils import UVUTensorProduct
+
+    torch.manual_seed(20)
+    h = UVUTensorProduct("32x0e+16x1o+8x2e", "0e+1o+2e", "32x0o+32x0e+16x1o+16x1e+8x2o+8x2e", mlp_input_size=4)
+    plan = h.tp.plan
+    n, e = 37, 900
+    ei = random_graph(n, e, 21, device)
+    o = ops.EdgeOrdering(ei, n)
+    x = torch.randn(n, plan.d_in, device=device, requires_grad=True)
+    y = torch.randn(e, plan.d_sh, device=device, requires_grad=True)
+    w = torch.randn(e, plan.w_numel, device=device, requires_grad=True)
+    out = ops.conv(x, y, w, plan, o, 0.3)
+    go = torch.randn_like(out)
+    dx, dy, dw = torch.autograd.grad(out, [x, y, w], go)
+
+    L = _lib.lib()
+    hd = plan.handle(x.device)
+    st = ops._stream()
+    ws = plan.workspace(x.device, e, True)
+    out2 = torch.full_like(out, float("nan"))
+    rp, eid, nbr = o.by_dst
+    P = ops._ptr
+    _lib.check(L.tfc_conv_fwd(hd, P(x), P(y), P(w), P(rp), P(eid), P(nbr), n, e, 0.3, P(out2), P(ws), st))
+    assert torch.equal(out2, out)
+    rp, eid, nbr = o.by_src
+    dx2, dy2, dw2 = (torch.full_like(t, float("nan")) for t in (dx, dy, dw))
+    _lib.check(L.tfc_conv_bwd(hd, P(x), P(y), P(w), P(go), P(rp), P(eid), P(nbr), n, e, 0.3, P(dx2), P(dw2), P(dy2), P(ws), st))
+    assert torch.equal(dx2, dx) and torch.equal(dw2, dw) and torch.equal(dy2, dy)
+    # plans that lay M out the same way share a signature; a different set of (l1, l2, l3) does not
+    h2 = UVUTensorProduct("8x0e+4x1o+2x2e", "0e+1o+2e", "8x0o+8x0e+4x1o+4x1e+2x2o+2x2e", mlp_input_size=4)
+    h3 = UVUTensorProduct("8x0e+4x1o", "0e+1o+2e", "8x0e+4x1o", mlp_input_size=4)
+    s1, s2, s3 = (int(L.tfc_conv_m_signature(p.tp.plan.handle(x.device))) for p in (h, h2, h3))
+    assert s1 == s2 and s1 != s3
+    assert L.tfc_conv_m_floats(hd, e) == L.tfc_conv_m_floats(h2.tp.plan.handle(x.device), e) > 0
+
+
+@pytest.mark.parametrize("n_rows", [1, 63, 200])
+def test_ir_transpose(device, n_rows):
+    """out[off*N + (m*N + n)*mul + u] = x[n, off + u*dim + m] for each (off, mul, dim) block; columns no
+    block covers are left alone."""
+    from matten_amd import ops
+
+    blocks = [(0, 5, 1), (5, 3, 3), (20, 7, 5), (55, 2, 7), (69, 64, 3)]  # gap at [14, 20)
+    d_row = 69 + 64 * 3
+    g = torch.Generator().manual_seed(30 + n_rows)
+    x = torch.randn(n_rows, d_row, generator=g).to(device)
+    got = ops._ir_transpose(x, blocks).cpu()
+    xc = x.cpu()
+    for off, mul, dim in blocks:
+        ref = xc[:, off : off + mul * dim].reshape(n_rows, mul, dim).permute(2, 0, 1).contiguous().reshape(-1)
+        assert torch.equal(got[off * n_rows : off * n_rows + ref.numel()], ref), (off, mul, dim)
+
+
+def test_ir_transpose_rejects_bad_blocks(device):
+    from matten_amd import _lib, ops
+
+    x = torch.randn(4, 10, device=device)
+    out = torch.empty(40, device=device)
+    arr = (_lib.IrBlock * 1)()
+    arr[0].off, arr[0].mul, arr[0].dim = 6, 2, 3  # runs past the row
+    assert _lib.lib().tfc_ir_transpose(ops._ptr(x), 4, 10, arr, 1, ops._ptr(out), ops._stream()) < 0
+
+
+def test_gemm_group_mixed_shapes(device):
+    """One tfc_gemm_group call over 19 problems that walk their operands in different ways (plain,
+    transposed, two-factor A, split K): each must equal its own product."""
+    from matten_amd import ops
+
+    g = torch.Generator().manual_seed(40)
+    descs, checks, keep = [], [], []
+    for i in range(19):
+        m, n, k = [(70, 33, 20), (128, 64, 512), (9, 200, 3000), (300, 12, 64)][i % 4]
+        m += i
+        A = torch.randn(m, k, generator=g)
+        B = torch.randn(k, n, generator=g)
+        kind = i % 3
+        c = torch.full((m, n), float("nan"), device=device)
+        if kind == 0:
+            a, b = A.to(device), B.to(device)
+            descs.append(ops._desc(m, n, k, ops._p(a), ops._p(b), ops._p(c), ops._lin(k), ops._lin(1), ops._lin(n), ops._lin(1), ops._lin(n), ops._lin(1), alpha=0.5))
+            ref = 0.5 * (A.double() @ B.double())
+        elif kind == 1:
+            a, b = A.t().contiguous().to(device), B.t().contiguous().to(device)
+            descs.append(ops._desc(m, n, k, ops._p(a), ops._p(b), ops._p(c), ops._lin(1), ops._lin(m), ops._lin(1), ops._lin(k), ops._lin(n), ops._lin(1)))
+            ref = A.double() @ B.double()
+        else:
+            # A[r, t] = a1[r, t] * a2[t]  (two factors, the second one constant along rows)
+            s = torch.randn(k, generator=g)
+            a, b, s_d = A.to(device), B.to(device), s.to(device)
+            keep.append(s_d)
+            descs.append(ops._desc(m, n, k, ops._p(a), ops._p(b), ops._p(c), ops._lin(k), ops._lin(1), ops._lin(n), ops._lin(1), ops._lin(n), ops._lin(1),
+                                   a2=ops._p(s_d), a2_r=ops._lin(0), a2_k=ops._lin(1)))
+            ref = (A.double() * s.double()[None]) @ B.double()
+        keep += [a, b]
+        checks.append((c, ref))
+    ops._gemm_group(descs)
+    for i, (c, ref) in enumerate(checks):
+        assert rel(c, ref) < TOL, i
+
+
+@pytest.mark.parametrize("d", [3, 5, 7])
+@pytest.mark.parametrize("n,mu,mv,mw", [(203, 16, 24, 8), (64, 64, 64, 64), (1000, 5, 7, 12)])
+def test_gemm_repeated_two_factor_operand(device, d, n, mu, mv, mw):
+    """a_rep: A[r, (u, w)] = sum_{k < d} x[k][r][u] * g[k][r][w] formed while staging (the attribute
+    gradient of the self connection), against the same sum in fp64."""
+    from matten_amd import ops
+
+    gen = torch.Generator().manual_seed(d * 1000 + n)
+    x = torch.randn(d, n, mu, generator=gen)
+    gg = torch.randn(d, n, mw, generator=gen)
+    W = torch.randn(mu, mv, mw, generator=gen)
+    ref = 0.7 * torch.einsum("knu,knw,uvw->nv", x.double(), gg.double(), W.double())
+    xd, gd, Wd = x.to(device), gg.to(device), W.to(device)
+    c = torch.full((n, mv), float("nan"), device=device)
+    ops._gemm_group([ops._desc(
+        n, mv, mu * mw, ops._p(xd), ops._p(Wd), ops._p(c),
+        a1_r=ops._lin(mu), a1_k=ops._imap(1, mw, 1, 0, 0),
+        a2=ops._p(gd), a2_r=ops._lin(mw), a2_k=ops._imap(1, mw, 0, 0, 1),
+        b_k=ops._imap(1, mw, mv * mw, 0, 1), b_j=ops._lin(mw), c_r=ops._lin(mv), c_j=ops._lin(1), alpha=0.7,
+        a_rep=d, a1_rs=n * mu, a2_rs=n * mw,
+    )])
+    assert rel(c, ref) < TOL
+
+
+def test_gemm_rejects_bad_repeat(device):
+    from matten_amd import _lib, ops
+
+    a = torch.randn(8, 8, device=device)
+    c = torch.empty(8, 8, device=device)
+    d = ops._desc(8, 8, 8, ops._p(a), ops._p(a), ops._p(c), ops._lin(8), ops._lin(1), ops._lin(8), ops._lin(1), ops._lin(8), ops._lin(1), a_rep=4)
+    arr = (_lib.GemmDesc * 1)(d)
+    assert _lib.lib().tfc_gemm_group(arr, 1, ops._stream()) < 0
+
+
+@pytest.mark.parametrize(
+    "hs,rows",
+    [
+        ([8, 64, 64, 100], 1),      # last width not a multiple of 64; a single row
+        ([8, 64, 64, 100], 127),
+        ([8, 33, 17, 52], 129),     # odd hidden widths, rows one past a 128-row block
+        ([5, 64, 64, 64, 64, 68], 300),  # four hidden layers
+        ([8, 16, 8], 1000),         # two layers
+        ([8, 64, 64, 1728], 0),     # no edges
+    ],
+)
+def test_radial_mlp_fused_edge_cases(device, hs, rows):
+    """tfc_radial_mlp_fwd at the corners of what it supports (the module takes it whenever
+    the hidden widths are <= 64 and the last width is a multiple of 4), forward and backward."""
+    from matten_amd.nn.e3 import FullyConnectedNet
+    from oracle import e3ref
+    from oracle.eigenn_ref import ssp
+
+    torch.manual_seed(50)
+    o = e3ref.FullyConnectedNet(hs, act=ssp, act_key="ssp").double()
+    h = FullyConnectedNet(hs, act="ssp")
+    _pair_state(o, h)
+    h = h.to(device)
+    x = torch.randn(rows, hs[0], dtype=torch.float64, requires_grad=True)
+    xg = x.detach().float().to(device).requires_grad_(True)
+    y, yg = o(x), h(xg)
+    assert yg.shape == y.shape
+    if rows == 0:
+        return
+    assert rel(yg, y) < TOL
+    go = torch.randn_like(y)
+    ref = torch.autograd.grad(y, [x] + list(o.parameters()), go)
+    got = torch.autograd.grad(yg, [xg] + list(h.parameters()), go.float().to(device))
+    for r, g_ in zip(ref, got):
+        assert rel(g_, r) < TOL
+
+
+def test_radial_mlp_fwd_unsupported_shapes_are_refused(device):
+    """The C entry point reports TFC_EUNSUPPORTED instead of computing something else."""
+    import ctypes as C
+
+    from matten_amd import _lib, ops
+
+    L = _lib.lib()
+    x = torch.randn(10, 8, device=device)
+    w0 = torch.randn(8, 128, device=device)
+    w1 = torch.randn(128, 64, device=device)
+    out = torch.empty(10, 64, device=device)
+    hid = torch.empty(10, 128, device=device)
+    dims = (C.c_int32 * 3)(8, 128, 64)
+    cw = (C.c_void_p * 2)(w0.data_ptr(), w1.data_ptr())
+    ch = (C.c_void_p * 2)(hid.data_ptr(), None)
+    rc = L.tfc_radial_mlp_fwd(ops._ptr(x), 10, 2, dims, cw, 1.0, ch, ops._ptr(out), ops._stream())
+    assert rc < 0 and L.tfc_last_error()
+
+
+def test_profile_modes(device):
+    """tfc_profile_enable(2) records the convolution kernels only; (1) records the others too."""
+    import ctypes as C
+
+    from matten_amd import _lib, ops
+    from matten_amd.nn.utils import UVUTensorProduct
+
+    L = _lib.lib()
+    h = UVUTensorProduct("8x0e+4x1o", "0e+1o+2e", "8x0e+4x1o", mlp_input_size=4)
+    n, e = 10, 50
+    ei = random_graph(n, e, 60, device)
+    x = torch.randn(n, h.tp.plan.d_in, device=device)
+    y = torch.randn(e, 9, device=device)
+    w = torch.randn(e, h.tp.plan.w_numel, device=device)
+    a = torch.randn(64, 64, device=device)
+    c = torch.empty(64, 64, device=device)
+
+    def names(mode):
+        L.tfc_profile_reset()
+        L.tfc_profile_enable(mode)
+        try:
+            ops.conv(x, y, w, h.tp.plan, ops.EdgeOrdering(ei, n), 1.0)
+            ops._gemm(64, 64, 64, ops._p(a), ops._p(a), ops._p(c), ops._lin(64), ops._lin(1), ops._lin(64), ops._lin(1), ops._lin(64), ops._lin(1), tag=b"gemm_test")
+        finally:
+            L.tfc_profile_enable(0)
+        buf = C.create_string_buffer(1 << 14)
+        assert L.tfc_profile_report(buf, len(buf)) >= 0
+        L.tfc_profile_reset()
+        return {ln.split()[0] for ln in buf.value.decode().splitlines()}
+
+    conv_only, everything = names(2), names(1)
+    assert conv_only and all(nm.startswith("tfc_conv_") for nm in conv_only)
+    assert conv_only < everything and "gemm_test" in everything

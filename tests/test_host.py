@@ -177,3 +177,34 @@ def test_ops_refuse_cpu_tensors():
 
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         Linear("4x0e", "4x0e")(torch.randn(3, 4))
+
+
+@pytest.mark.parametrize("with_hint", [True, False])
+def test_attr_factors_host_logic(with_hint):
+    """The factorisation a = C R behind the low-rank self connection (matten_amd/ops.py
+    attr_factors) is host-side torch: exact reconstruction, refusal when it would not pay, and the
+    cache keyed on (address, version) noticing an in-place update."""
+    from matten_amd import ops
+
+    g = torch.Generator().manual_seed(0)
+    table = torch.randn(5, 32, generator=g)
+    idx = torch.randint(0, 5, (100,), generator=g)
+    a = table[idx].contiguous()
+    f = ops.attr_factors(a, idx if with_hint else None)
+    assert f is not None
+    Cm, Rm = f
+    assert Cm.shape == (100, 8) and Rm.shape == (8, 32)  # 5 classes padded to a multiple of 4
+    assert torch.equal(Cm @ Rm, a) and torch.equal(Cm.sum(1), torch.ones(100))
+    assert ops.attr_factors(a, idx if with_hint else None) is f  # cached
+    a.mul_(2.0)  # version bump: factors are rebuilt
+    f2 = ops.attr_factors(a, idx if with_hint else None)
+    assert f2 is not f and torch.equal(f2[0] @ f2[1], a)
+    # too few rows, too narrow, or too many distinct rows: dense route
+    assert ops.attr_factors(a[:10].contiguous(), idx[:10] if with_hint else None) is None
+    assert ops.attr_factors(torch.randn(100, 4), None) is None
+    many = torch.randn(100, 32, generator=g)
+    assert ops.attr_factors(many, torch.arange(100) if with_hint else None) is None
+    if not with_hint:
+        nan_rows = a.clone()
+        nan_rows[3, 0] = float("nan")
+        assert ops.attr_factors(nan_rows) is None  # NaN rows never verify as copies
