@@ -43,6 +43,7 @@ def make_crystal(n: int, a: float, sigma: float = 0.05, r_cut: float = 5.0, seed
 def collate(graphs: Sequence[Dict[str, np.ndarray]], device="cpu") -> Dict[str, torch.Tensor]:
     pos, cell, z, ei, sh, batch, nn = [], [], [], [], [], [], []
     off = 0
+    ptr = [0]
     for g, gr in enumerate(graphs):
         n = len(gr["pos"])
         pos.append(torch.as_tensor(gr["pos"], dtype=torch.float32))
@@ -53,6 +54,7 @@ def collate(graphs: Sequence[Dict[str, np.ndarray]], device="cpu") -> Dict[str, 
         nn.append(torch.as_tensor(gr["num_neigh"], dtype=torch.float32))
         batch.append(torch.full((n,), g, dtype=torch.int64))
         off += n
+        ptr.append(off)
     out = {
         K.POSITIONS: torch.cat(pos),
         K.CELL: torch.cat(cell),  # [3G, 3]
@@ -61,6 +63,7 @@ def collate(graphs: Sequence[Dict[str, np.ndarray]], device="cpu") -> Dict[str, 
         K.EDGE_CELL_SHIFT: torch.cat(sh),
         K.BATCH: torch.cat(batch),
         "num_neigh": torch.cat(nn),
+        "ptr": torch.tensor(ptr, dtype=torch.int64),  # PyG's graph boundaries: nodes of graph g are ptr[g]:ptr[g+1]
     }
     return {k: v.to(device) for k, v in out.items()}
 
