@@ -67,3 +67,48 @@ def train_trajectory(model, graphs, targets, device, dtype, epochs=2, batch_size
             opt.step()
             losses.append(loss.item())
     return losses
+
+
+LSDI_FIXTURE = os.path.join(ROOT, "tests", "golden", "lsdi_nmr_n20_structures.json")
+
+
+def load_lsdi():
+    """configs[1]'s data: one data point per NMR tensor (eigenn/dataset/LSDI.py:69-88: node mask with the
+    tensor's site set, tensor symmetrised), graphs at r_cut 5; returns graphs, per-point masks [N] bool and
+    targets [1,3,3] fp64, and the dataset hparams (LSDI.py get_to_model_info = matbench's)."""
+    import numpy as np
+
+    from matten_amd.data.structures import dataset_hparams, graphs_from_records
+
+    entries = json.load(open(LSDI_FIXTURE))
+    per_entry = graphs_from_records(entries, 5.0)
+    graphs, masks, targets = [], [], []
+    for e, g in zip(entries, per_entry):
+        for t, site in zip(e["tensors"], e["ind"]):
+            m = np.zeros(len(e["pos"]), dtype=bool)
+            m[site] = True
+            t = torch.tensor(t, dtype=torch.float64)
+            graphs.append(g)
+            masks.append(torch.from_numpy(m))
+            targets.append(((t + t.T) / 2).reshape(1, 3, 3))
+    return graphs, masks, targets, dataset_hparams(graphs)
+
+
+def tensor_train_trajectory(model, graphs, masks, targets, device, dtype, epochs=2, batch_size=10, lr=1e-3):
+    """minimal_atomic.yaml's loop: L1Loss between tensor_output [n_selected,3,3] and the targets, Adam."""
+    model = model.to(device=device, dtype=dtype)
+    opt = torch.optim.Adam(model.parameters(), lr=lr)
+    losses = []
+    for _ in range(epochs):
+        for s in range(0, len(graphs), batch_size):
+            ids = list(range(s, min(s + batch_size, len(graphs))))
+            b = make_batch(graphs, ids, device, dtype)
+            b["node_masks"] = torch.cat([masks[i] for i in ids]).to(device)
+            y = torch.cat([targets[i] for i in ids]).to(device=device, dtype=dtype)
+            out = model(b)["tensor_output"]
+            loss = torch.nn.functional.l1_loss(out, y)
+            opt.zero_grad()
+            loss.backward()
+            opt.step()
+            losses.append(loss.item())
+    return losses

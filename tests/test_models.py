@@ -246,3 +246,29 @@ def test_training_trajectory_vs_oracle(device, dataset):
     for k, v in p.state_dict().items():
         if v.is_floating_point():
             assert rel_err(v, so[k]) < 1e-3, k
+
+
+def test_lsdi_fixture_unpacks_like_the_reference():
+    """20 entries (24x4, 9x4, 60x4, 28x8 atoms), 1 tensor each except 3 for the 60-atom
+    ones -> 28 data points, each with exactly one selected site and a symmetric target."""
+    graphs, masks, targets, hp = M.load_lsdi()
+    assert len(graphs) == 28 and hp["allowed_species"] == (8, 12, 14, 20)
+    assert sorted({len(g["pos"]) for g in graphs}) == [9, 24, 28, 60]
+    assert all(int(m.sum()) == 1 for m in masks)
+    assert all(torch.equal(t, t.transpose(1, 2)) and t.shape == (1, 3, 3) for t in targets)
+
+
+@pytest.mark.gpu
+def test_atomic_tensor_training_trajectory_vs_oracle(device):
+    """configs[1] (minimal_atomic.yaml on the LSDI NMR fixture, 1 GPU): 2 epochs x 3 batches of L1Loss on the
+    selected sites' symmetric tensors, HIP path against the fp64 oracle, same tolerance as the energy run."""
+    graphs, masks, targets, hp = M.load_lsdi()
+    torch.manual_seed(35)
+    o = M.build("oracle", "tensor", hp)
+    state = {k: v.clone() for k, v in o.state_dict().items()}
+    ref = M.tensor_train_trajectory(o, graphs, masks, targets, "cpu", torch.float64)
+    p = M.build("hip", "tensor", hp)
+    p.load_state_dict(state, strict=True)
+    got = M.tensor_train_trajectory(p, graphs, masks, targets, device, torch.float32)
+    print("oracle fp64:", ref, "\nhip  fp32:", got)
+    assert len(ref) == 6 and np.allclose(got, ref, rtol=1e-4)
