@@ -27,4 +27,8 @@ BATCH = "batch"
 # attributes, equal class => identical NODE_ATTRS row (for a species embedding: the species index).
 # When present the self connection takes its low-rank route without having to discover the classes
 # (which costs host synchronisations); when absent they are discovered from NODE_ATTRS itself.
+# Supplying it is a promise that NODE_ATTRS = table[classes] for some row table: the gradient the
+# self connection returns for NODE_ATTRS is then the class mean of the per-node gradient (its
+# projection onto tensors of that form), which hands `table` exactly the reference's gradient at
+# a fraction of the cost; per-node attribute gradients need the key left out.
 NODE_ATTRS_CLASSES = "node_attrs_classes"

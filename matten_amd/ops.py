@@ -13,7 +13,7 @@ import functools
 import math
 import weakref
 from dataclasses import dataclass
-from typing import List, Optional, Sequence, Tuple
+from typing import List, NamedTuple, Optional, Sequence, Tuple
 
 import torch
 
@@ -825,6 +825,17 @@ _ATTR_CLASSES: "dict[tuple, tuple]" = {}
 _HASH_COEF: "dict[tuple, torch.Tensor]" = {}
 
 
+class AttrFactors(NamedTuple):
+    """a = C @ R (attr_factors).  `promised`: the caller supplied the classes and thereby promised
+    that `a` is a per-class row table looked up by class, which lets the backward return the
+    gradient of `a` projected onto such tensors (the class mean) instead of the per-node one."""
+    C: torch.Tensor          # [N, r] one-hot, fp32
+    R: torch.Tensor          # [r, d_a] distinct rows (zero padded)
+    inv: torch.Tensor        # [N] int64 class of each row
+    inv_count: torch.Tensor  # [r] fp32, 1 / rows in the class (0-size classes: 1)
+    promised: bool
+
+
 def _class_structure(labels: torch.Tensor):
     """(inv [N] dense class ids, rep [u] first row of each class, one-hot C [N, r], u, r) of an
     integer labelling; one host sync (the number of classes)."""
@@ -874,7 +885,7 @@ def attr_factors(a: torch.Tensor, classes: Optional[torch.Tensor] = None):
         with torch.no_grad():
             R = torch.zeros(r, d_a, dtype=torch.float32, device=a.device)
             R[:u] = a.detach()[rep]
-        res = (Cm, R)
+        res = AttrFactors(Cm, R, inv, 1.0 / Cm.sum(0).clamp_min(1.0), True)
     else:
         key = (a.data_ptr(), a._version, tuple(a.shape), None)
         fhit = _ATTR_FACTORS.get(key)
@@ -895,7 +906,7 @@ def attr_factors(a: torch.Tensor, classes: Optional[torch.Tensor] = None):
                 if bool((rows[inv] == a.detach()).all().item()):  # sync; also rejects NaN rows
                     R = torch.zeros(r, d_a, dtype=torch.float32, device=a.device)
                     R[:u] = rows
-                    res = (Cm, R)
+                    res = AttrFactors(Cm, R, inv, 1.0 / Cm.sum(0).clamp_min(1.0), False)
     if len(_ATTR_FACTORS) >= 8:
         _ATTR_FACTORS.pop(next(iter(_ATTR_FACTORS)))
     _ATTR_FACTORS[key] = (a, res)
@@ -933,7 +944,7 @@ class _FctpFn(torch.autograd.Function):
             ctx.save_for_backward(x, a, weight)
             ctx.low = None
         else:
-            Cm, R = factors
+            Cm, R = factors.C, factors.R
             r = Cm.shape[1]
             # W'[u, s, w] = sum_v R[s, v] W[u, v, w], per instruction
             low_ins, off = [], 0
@@ -952,6 +963,7 @@ class _FctpFn(torch.autograd.Function):
             _fctp_fwd(n, x, Cm, r, wp, out, spec, low_ins, on_base)
             ctx.save_for_backward(x, a, weight, Cm, R, wp)
             ctx.low = tuple(low_ins)
+            ctx.factors = factors
         ctx.spec = spec
         ctx.has_base = base is not None
         return out
@@ -975,26 +987,47 @@ class _FctpFn(torch.autograd.Function):
                 _fctp_dx(n, a, spec.d_a, weight, gt, dx, spec, spec.instructions)
             else:
                 _fctp_dx(n, Cm, Cm.shape[1], wp, gt, dx, spec, ctx.low)
-        if ctx.needs_input_grad[1]:
+        project_da = ctx.low is not None and ctx.factors.promised and ctx.needs_input_grad[1]
+        if ctx.needs_input_grad[1] and not project_da:
             xt = _ir_transpose(x, [(xo, mu, d) for xo, mu, _, _, _, _, d, _, _ in spec.instructions])
             da = _fctp_da(n, xt, weight, gt, spec, spec.instructions, spec.d_a, spec.a_covered)
-        if ctx.needs_input_grad[2]:
-            dw = torch.empty_like(weight)
+        if ctx.needs_input_grad[2] or project_da:
             if ctx.low is None:
+                dw = torch.empty_like(weight)
                 _fctp_dw(n, x, a, spec.d_a, gt, dw, spec, spec.instructions)
             else:
                 r = Cm.shape[1]
                 dwp = torch.empty_like(wp)
                 _fctp_dw(n, x, Cm, r, gt, dwp, spec, ctx.low)
-                # dW[u, v, w] = sum_s R[s, v] dW'[u, s, w]
-                _gemm_group([
-                    _desc(
-                        mv, mu * mw, r, _p(R, ao), _p(dwp, lo[7]), _p(dw, wo),
-                        a1_r=_lin(1), a1_k=_lin(spec.d_a), b_k=_lin(mw), b_j=_imap(1, mw, r * mw, 0, 1),
-                        c_r=_lin(mw), c_j=_imap(1, mw, mv * mw, 0, 1), tag=b"gemm_fctp_lowrank_w",
-                    )
-                    for (xo, mu, ao, mv, oo, mw, d, wo, alpha), lo in zip(spec.instructions, ctx.low)
-                ])
+                if ctx.needs_input_grad[2]:
+                    # dW[u, v, w] = sum_s R[s, v] dW'[u, s, w]
+                    dw = torch.empty_like(weight)
+                    _gemm_group([
+                        _desc(
+                            mv, mu * mw, r, _p(R, ao), _p(dwp, lo[7]), _p(dw, wo),
+                            a1_r=_lin(1), a1_k=_lin(spec.d_a), b_k=_lin(mw), b_j=_imap(1, mw, r * mw, 0, 1),
+                            c_r=_lin(mw), c_j=_imap(1, mw, mv * mw, 0, 1), tag=b"gemm_fctp_lowrank_w",
+                        )
+                        for (xo, mu, ao, mv, oo, mw, d, wo, alpha), lo in zip(spec.instructions, ctx.low)
+                    ])
+                if project_da:
+                    # dR[s, v] = sum_{u,w} dW'[u, s, w] W[u, v, w]: the gradient of the distinct rows; every row
+                    # of a class then receives its class mean (sums back to dR through any lookup a = R[class])
+                    ni = len(spec.instructions)
+                    part = torch.empty(ni, r, spec.d_a, dtype=torch.float32, device=x.device)
+                    if not spec.a_covered or any(ins[3] != spec.d_a for ins in spec.instructions):
+                        part.zero_()
+                    _gemm_group([
+                        _desc(
+                            r, mv, mu * mw, _p(dwp, lo[7]), _p(weight, wo), _p(part, i * r * spec.d_a + ao),
+                            a1_r=_lin(mw), a1_k=_imap(1, mw, r * mw, 0, 1),
+                            b_k=_imap(1, mw, mv * mw, 0, 1), b_j=_lin(mw), c_r=_lin(spec.d_a), c_j=_lin(1),
+                            tag=b"gemm_fctp_da_rows",
+                        )
+                        for i, ((xo, mu, ao, mv, oo, mw, d, wo, alpha), lo) in enumerate(zip(spec.instructions, ctx.low))
+                    ])
+                    d_rows = (part.sum(dim=0) if ni > 1 else part[0]) * ctx.factors.inv_count[:, None]
+                    da = d_rows[ctx.factors.inv]
         return dx, da, dw, None, (g if ctx.has_base else None), None
 
 

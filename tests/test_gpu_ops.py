@@ -176,7 +176,7 @@ def test_fctp_low_rank_route_vs_oracle(device, n_distinct):
     xg, ag, bg = (t.detach().float().to(device).requires_grad_(True) for t in (x, a, base))
     f = ops.attr_factors(ag)
     if 2 * max(4, (n_distinct + 3) // 4 * 4) <= 32:
-        assert f is not None and torch.equal(f[0] @ f[1], ag.detach())
+        assert f is not None and not f.promised and torch.equal(f.C @ f.R, ag.detach())
     else:
         assert f is None
     y = base + o(x, a)
@@ -187,6 +187,46 @@ def test_fctp_low_rank_route_vs_oracle(device, n_distinct):
     got = torch.autograd.grad(yg, [xg, ag, h.weight, bg], go.float().to(device))
     for r, g_ in zip(ref, got):
         assert rel(g_, r) < TOL
+
+
+@pytest.mark.parametrize("n_distinct", [1, 4, 7])
+def test_fctp_promised_classes_project_attr_gradient(device, n_distinct):
+    """With keys.NODE_ATTRS_CLASSES supplied the caller promises a = table[classes]; the attribute
+    gradient is then returned projected onto such tensors: every row gets the mean of the dense
+    gradient over its class, so the table behind the lookup receives exactly the dense gradient.
+    All other results are unchanged."""
+    from matten_amd.nn.e3 import FullyConnectedTensorProduct
+    from oracle import e3ref
+
+    in1, in2, out = "16x0e+8x1o+8x2e", "32x0e", "16x0o+40x0e+8x1o+8x1e+8x2o+8x2e"
+    torch.manual_seed(12)
+    o = e3ref.FullyConnectedTensorProduct(in1, in2, out).double()
+    h = FullyConnectedTensorProduct(in1, in2, out)
+    _pair_state(o, h)
+    h = h.to(device)
+    n = 150
+    table = torch.randn(n_distinct, 32, dtype=torch.float64, requires_grad=True)
+    idx = torch.randint(0, n_distinct, (n,))
+    idx[:n_distinct] = torch.arange(n_distinct)
+    x = torch.randn(n, o.irreps_in1.dim, dtype=torch.float64, requires_grad=True)
+    a = table[idx]
+    a.retain_grad()
+    y = o(x, a)
+    go = torch.randn_like(y)
+    gx, gt_, gw = torch.autograd.grad(y, [x, table, o.weight], go, retain_graph=True)
+    (ga,) = torch.autograd.grad(y, [a], go)
+    tg = table.detach().float().to(device).requires_grad_(True)
+    xg = x.detach().float().to(device).requires_grad_(True)
+    idx_d = idx.to(device)
+    ag = tg[idx_d]
+    yg = h(xg, ag, classes=idx_d)
+    assert rel(yg, y) < TOL
+    gxg, gtg, gwg, gag = torch.autograd.grad(yg, [xg, tg, h.weight, ag], go.float().to(device))
+    assert rel(gxg, gx) < TOL and rel(gwg, gw) < TOL
+    assert rel(gtg, gt_) < TOL  # the table gradient is the dense one
+    onehot = torch.nn.functional.one_hot(idx, n_distinct).double()
+    class_mean = (onehot / onehot.sum(0)) @ (onehot.T @ ga)
+    assert rel(gag, class_mean) < TOL
 
 
 @pytest.mark.parametrize("hs", [[8, 64, 64, 96], [8, 64, 384], [4, 8, 24], [8, 64, 64, 1728]])

@@ -192,13 +192,14 @@ def test_attr_factors_host_logic(with_hint):
     a = table[idx].contiguous()
     f = ops.attr_factors(a, idx if with_hint else None)
     assert f is not None
-    Cm, Rm = f
+    Cm, Rm = f.C, f.R
+    assert f.promised == with_hint and torch.equal(f.inv_count[:5] * Cm.sum(0)[:5], torch.ones(5))
     assert Cm.shape == (100, 8) and Rm.shape == (8, 32)  # 5 classes padded to a multiple of 4
     assert torch.equal(Cm @ Rm, a) and torch.equal(Cm.sum(1), torch.ones(100))
     assert ops.attr_factors(a, idx if with_hint else None) is f  # cached
     a.mul_(2.0)  # version bump: factors are rebuilt
     f2 = ops.attr_factors(a, idx if with_hint else None)
-    assert f2 is not f and torch.equal(f2[0] @ f2[1], a)
+    assert f2 is not f and torch.equal(f2.C @ f2.R, a)
     # too few rows, too narrow, or too many distinct rows: dense route
     assert ops.attr_factors(a[:10].contiguous(), idx[:10] if with_hint else None) is None
     assert ops.attr_factors(torch.randn(100, 4), None) is None
