@@ -126,9 +126,15 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="c3", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse N ranks on one GPU)")
+    ap.add_argument("--overlap", type=int, default=0, help="1: launch the gradient all-reduce in slices from grad hooks during backward (not yet timed over RCCL, see tools/rehearse_dp.py)")
     ap.add_argument("--check", action="store_true", help="also verify a small case against the oracle before timing")
     args = ap.parse_args()
 
+    if os.environ.get("TFC_BENCH_WATCHDOG"):  # debugging aid: dump every thread's stack and exit after N seconds
+        import faulthandler
+
+        faulthandler.dump_traceback_later(int(os.environ["TFC_BENCH_WATCHDOG"]), exit=True)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -140,8 +146,12 @@ def main():
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            local_rank %= max(torch.cuda.device_count(), 1)  # rehearsal: ranks may share a card
+            dist.init_process_group(backend=args.backend)
     device = torch.device("cuda", local_rank)
     torch.cuda.set_device(device)
 
@@ -166,12 +176,14 @@ def main():
     model = model.to(device)
     params = list(model.parameters())
 
-    # one flat gradient bucket; param.grad are views into it => one all-reduce, no copies
+    # one flat gradient buffer; param.grad are views into it => collectives on slices of it, no copies,
+    # launched from grad hooks so that they overlap with the rest of backward
     from matten_amd.dp import FlatGradBucket
 
-    bucket = FlatGradBucket(params)
+    bucket = FlatGradBucket(params, overlap=bool(args.overlap), bucket_bytes=int(os.environ.get("TFC_BUCKET_BYTES", 8 << 20)))
 
     pos0 = batch[K.POSITIONS]
+    _SYNC_BEFORE_AR = bool(os.environ.get("TFC_SYNC_BEFORE_AR"))  # rehearsal aid
 
     def step():
         bucket.zero()
@@ -180,6 +192,8 @@ def main():
         b[K.POSITIONS] = pos
         _, energy, _ = model(b, wl["graphs"])
         energy.sum().backward()
+        if _SYNC_BEFORE_AR:
+            torch.cuda.synchronize()
         bucket.all_reduce_mean()
         return pos.grad  # = -forces
 
@@ -193,7 +207,7 @@ def main():
     sync()
     L = _lib.lib()
     L.tfc_profile_reset()
-    L.tfc_profile_enable(2)  # HIP events around the conv kernels only, on their launch stream
+    L.tfc_profile_enable(0 if os.environ.get("TFC_BENCH_NOPROF") else 2)  # HIP events around the conv kernels only, on their launch stream
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
@@ -281,7 +295,7 @@ def main():
                 "edges_per_gpu": n_edges,
                 "conv_layers": wl["layers"],
                 "step": "edge encoders + 3 conv layers forward, backward to all parameters and positions (forces)"
-                + (", flat RCCL gradient all-reduce" if world > 1 else ""),
+                + (f", gradient all-reduce ({args.backend}) in {len(bucket.bounds)} slices" + (" overlapped with backward" if args.overlap else " after backward") if world > 1 else ""),
                 "parallelism": f"dp{world}",
                 "layer_shapes": shapes,
             },

@@ -9,9 +9,14 @@ bucketed gradient all-reduce.  The forward/backward of the hot path needs no com
 """
 from __future__ import annotations
 
-from typing import Iterable, List, Sequence
+from typing import Iterable, List, Sequence, Tuple
+
+import os
+import sys
 
 import torch
+
+_DEBUG = bool(os.environ.get("TFC_DP_DEBUG"))
 
 
 def shard_graphs(n_graphs: int, rank: int, world: int) -> List[int]:
@@ -20,13 +25,24 @@ def shard_graphs(n_graphs: int, rank: int, world: int) -> List[int]:
 
 
 class FlatGradBucket:
-    """All parameter gradients as views into one contiguous buffer.
+    """All parameter gradients as views into one contiguous buffer, reduced in a few large slices
+    that overlap with the rest of the backward pass.
 
     `param.grad` of every parameter aliases a slice of `flat`, so autograd accumulates straight
-    into the bucket and `all_reduce_mean()` is a single collective on a single tensor with no
-    gather/scatter copies."""
+    into the buffer and a collective runs on a slice of it with no gather/scatter copies.  The
+    buffer is laid out in REVERSE registration order (the order in which backward finishes the
+    gradients: last layer first) and cut into slices of at least `bucket_bytes`; a slice's
+    all-reduce is launched (async, on the backend's own stream) from a post-accumulate hook as
+    soon as its last gradient has been written, in slice order on every rank, while the earlier
+    layers are still in backward.  `all_reduce_mean()` launches whatever is left (slices whose
+    parameters got no gradient), waits and divides.  With `overlap=False` there are no hooks and
+    the buffer is one slice: a single all-reduce after backward.
 
-    def __init__(self, params: Iterable[torch.nn.Parameter]):
+    xGMI is point to point and a ring all-reduce is per-link bound, so slices are
+    kept large: the default cap of 8 MB gives 3 slices at config 3 (22 MB of gradients), of which
+    only the last, smallest one (the first layer's) is exposed after backward ends."""
+
+    def __init__(self, params: Iterable[torch.nn.Parameter], bucket_bytes: int = 8 << 20, overlap: bool = True, group=None):
         self.params = [p for p in params if p.requires_grad]
         if not self.params:
             raise ValueError("no trainable parameters")
@@ -35,21 +51,74 @@ class FlatGradBucket:
             if p.device != dev or p.dtype != dt:
                 raise ValueError("all parameters must share device and dtype")
         self.flat = torch.zeros(sum(p.numel() for p in self.params), dtype=dt, device=dev)
-        off = 0
-        for p in self.params:
+        self.group = group
+        self.overlap = overlap
+        self.bounds: List[Tuple[int, int]] = []  # [begin, end) of each slice in `flat`
+        self._slice_of = {}
+        self._n_in_slice: List[int] = []
+        off = begin = count = 0
+        item = self.flat.element_size()
+        for p in reversed(self.params):
             p.grad = self.flat[off : off + p.numel()].view_as(p)
+            self._slice_of[id(p)] = len(self.bounds)
             off += p.numel()
+            count += 1
+            if overlap and (off - begin) * item >= bucket_bytes:  # (no overlap: one collective on the whole buffer)
+                self.bounds.append((begin, off))
+                self._n_in_slice.append(count)
+                begin, count = off, 0
+        if count:
+            self.bounds.append((begin, off))
+            self._n_in_slice.append(count)
+        self._pending = list(self._n_in_slice)
+        self._works: List[object] = [None] * len(self.bounds)
+        self._next = 0
+        self._hooks = [p.register_post_accumulate_grad_hook(self._on_grad) for p in self.params] if overlap else []
 
-    def zero(self):
-        self.flat.zero_()
-
-    def all_reduce_mean(self, group=None):
+    # ---- internals
+    def _active(self) -> bool:
         import torch.distributed as dist
 
-        if not (dist.is_available() and dist.is_initialized()):
+        return dist.is_available() and dist.is_initialized() and dist.get_world_size(self.group) > 1
+
+    def _launch(self, i: int):
+        import torch.distributed as dist
+
+        b, e = self.bounds[i]
+        self._works[i] = dist.all_reduce(self.flat[b:e], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+
+    def _on_grad(self, p):
+        i = self._slice_of[id(p)]
+        self._pending[i] -= 1
+        if not self._active():
             return
-        world = dist.get_world_size(group)
-        if world == 1:
+        # strictly in slice order, so that every rank issues the same sequence of collectives
+        while self._next < len(self.bounds) and self._pending[self._next] == 0 and self._works[self._next] is None:
+            self._launch(self._next)
+            self._next += 1
+
+    # ---- per step
+    def zero(self):
+        """Start of a step: clears the gradients and re-arms the slices."""
+        self.flat.zero_()
+        self._pending = list(self._n_in_slice)
+        self._works = [None] * len(self.bounds)
+        self._next = 0
+
+    def all_reduce_mean(self, group=None):
+        """End of backward: every gradient becomes the mean over the ranks."""
+        if group is not None:
+            self.group = group
+        if not self._active():
             return
-        dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=group)
-        self.flat.div_(world)
+        import torch.distributed as dist
+
+        for i in range(len(self.bounds)):
+            if self._works[i] is None:
+                self._launch(i)
+        for i, w in enumerate(self._works):
+            if _DEBUG:
+                print(f"[dp] wait slice {i} {self.bounds[i]}", file=sys.stderr, flush=True)
+            w.wait()
+        self._next = len(self.bounds)
+        self.flat.div_(dist.get_world_size(self.group))
