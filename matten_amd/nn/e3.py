@@ -41,6 +41,11 @@ def _n2m(name: str) -> float:
     return 1.0 if abs(c - 1.0) < 1e-4 else c
 
 
+def _row_blocks(irreps: Irreps):
+    """(offset, mul, 2l+1) of every non-empty block of a feature row."""
+    return tuple((off, m.mul, m.ir.dim) for off, m in zip(irreps.offsets(), irreps) if m.dim > 0)
+
+
 class Linear(torch.nn.Module):
     """o3.Linear(irreps_in, irreps_out): one weight block [mul_in, mul_out] per pair of equal
     irreps (loop order in, out), flattened into a 1-D `weight`; path weight
@@ -75,6 +80,7 @@ class Linear(torch.nn.Module):
             instructions=tuple(ins),
             out_covered=all(b in covered_out or self.irreps_out[b].dim == 0 for b in range(len(self.irreps_out))),
             in_covered=all(a in covered_in or self.irreps_in[a].dim == 0 for a in range(len(self.irreps_in))),
+            out_blocks=_row_blocks(self.irreps_out),
         )
 
     def forward(self, x):
@@ -131,6 +137,7 @@ class FullyConnectedTensorProduct(torch.nn.Module):
             out_covered=cov(self.irreps_out, {c for _, _, c in triples}),
             x_covered=cov(self.irreps_in1, {a for a, _, _ in triples}),
             a_covered=cov(self.irreps_in2, {b for _, b, _ in triples}),
+            out_blocks=_row_blocks(self.irreps_out),
         )
 
     def forward(self, x, a, base: Optional[torch.Tensor] = None, classes: Optional[torch.Tensor] = None):

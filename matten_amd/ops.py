@@ -541,16 +541,28 @@ def _gemm_waves(items):
         _gemm_group(group)
 
 
+_TRANSPOSED: "dict[tuple, tuple]" = {}
+
+
 def _ir_transpose(t: torch.Tensor, blocks) -> torch.Tensor:
     """Channel-contiguous copy of the (off, mul, dim) blocks of the rows of `t` (tfc_ir_transpose):
-    block b of the flat result starts at off_b * N and is laid out [dim_b][N][mul_b]."""
+    block b of the flat result starts at off_b * N and is laid out [dim_b][N][mul_b].  The last two
+    results are kept (with their source, so its address cannot be reused): the gradient that reaches
+    the self connection and linear_2 of a layer is one tensor, transposed once."""
     n, d_row = t.shape
-    blocks = sorted(set(blocks))
+    blocks = tuple(sorted(set(blocks)))
+    key = (t.data_ptr(), t._version, n, d_row, blocks)
+    hit = _TRANSPOSED.get(key)
+    if hit is not None:
+        return hit[1]
     arr = (IrBlock * len(blocks))()
     for a, (off, mul, dim) in zip(arr, blocks):
         a.off, a.mul, a.dim = off, mul, dim
     out = torch.empty(max(n * d_row, 1), dtype=torch.float32, device=t.device)
     _lib.check(_lib.lib().tfc_ir_transpose(_ptr(t), n, d_row, arr, len(blocks), _ptr(out), _stream()))
+    while len(_TRANSPOSED) >= 2:
+        _TRANSPOSED.pop(next(iter(_TRANSPOSED)))
+    _TRANSPOSED[key] = (t.detach(), out)
     return out
 
 
@@ -571,6 +583,7 @@ class LinearSpec:
     instructions: Tuple[Tuple[int, int, int, int, int, int, float], ...]
     out_covered: bool  # every output column is written by some instruction
     in_covered: bool
+    out_blocks: Tuple[Tuple[int, int, int], ...] = ()  # every (off, mul, dim) block of the output row
 
 
 class _LinearFn(torch.autograd.Function):
@@ -607,7 +620,9 @@ class _LinearFn(torch.autograd.Function):
         spec, n = ctx.spec, ctx.n
         g = _f32(g, "grad_output")
         dx = dw = None
-        gt = _ir_transpose(g, [(out_off, mo, d) for _, _, out_off, mo, d, _, _ in spec.instructions])
+        # (all blocks of the row, not only the ones reached: the copy is then shared with the other
+        # consumer of the same gradient, see _ir_transpose)
+        gt = _ir_transpose(g, spec.out_blocks or [(out_off, mo, d) for _, _, out_off, mo, d, _, _ in spec.instructions])
         if ctx.needs_input_grad[0]:
             alloc = torch.empty if spec.in_covered else torch.zeros
             dx = alloc(n, spec.d_in, dtype=torch.float32, device=g.device)
@@ -736,6 +751,7 @@ class FctpSpec:
     out_covered: bool
     x_covered: bool
     a_covered: bool
+    out_blocks: Tuple[Tuple[int, int, int], ...] = ()  # every (off, mul, dim) block of the output row
 
 
 def _fctp_fwd(n, x, a, d_a, weight, out, spec, ins_list, on_base):
@@ -980,7 +996,7 @@ class _FctpFn(torch.autograd.Function):
         dx = da = dw = None
         # channel-contiguous copies ([dim][N][mul] per block): the contractions below all run over
         # channels, which e3nn's [mul][dim] blocks hold at stride dim
-        gt = _ir_transpose(g, [(oo, mw, d) for _, _, _, _, oo, mw, d, _, _ in spec.instructions])
+        gt = _ir_transpose(g, spec.out_blocks or [(oo, mw, d) for _, _, _, _, oo, mw, d, _, _ in spec.instructions])
         if ctx.needs_input_grad[0]:
             dx = (torch.empty if spec.x_covered else torch.zeros)(n, spec.d_x, dtype=torch.float32, device=x.device)
             if ctx.low is None:
