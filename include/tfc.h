@@ -271,6 +271,42 @@ int tfc_radial_mlp_fwd(const float* x, int64_t n_rows, int32_t n_layers, const i
                        const float* const* weights, float act_cst, float* const* hidden, float* out,
                        tfc_stream_t stream);
 
+/* Backward of the radial FullyConnectedNet (what autograd derives from eigenn/nn/utils.py:247-252,262).
+ * Arguments as for the forward; `hidden` are the forward's saved activations, `gout` [n_rows,
+ * dims[n_layers]] the gradient of the output.  dhidden[i] [n_rows, dims[i+1]] (i < n_layers - 1) is
+ * caller scratch that receives the gradient of the pre-activation-scaled hidden layer; dx (nullable)
+ * [n_rows, dims[0]] the gradient of the input; dweights[i] (nullable entries) [dims[i], dims[i+1]]
+ * the weight gradients, all formed by ONE grouped launch at the end.  `workspace`: optional split-K
+ * scratch of tfc_radial_mlp_bwd_workspace_floats floats (null: the long-K products are not split). */
+int64_t tfc_radial_mlp_bwd_workspace_floats(int64_t n_rows, int32_t n_layers, const int32_t* dims);
+int tfc_radial_mlp_bwd(const float* x, int64_t n_rows, int32_t n_layers, const int32_t* dims,
+                       const float* const* weights, float act_cst, const float* const* hidden,
+                       const float* gout, float* const* dhidden, float* dx, float* const* dweights,
+                       float* workspace, int64_t workspace_floats, tfc_stream_t stream);
+
+/* o3.Linear (eigenn/nn/point_conv.py:56-61,79 linear_1; :130-135,180 linear_2; eigenn/nn/nodewise.py:112-117):
+ * one tfc_linear_ins per e3nn instruction (a pair of equal irreps, in e3nn's order):
+ *     out[n, out_off + w*dim + k] (+)= path_weight * sum_u x[n, in_off + u*dim + k] * W[w_off + u*mul_out + w]
+ * forward: x [n_rows, d_in] -> out [n_rows, d_out]; columns of out that no instruction writes are
+ * left untouched (zero them beforehand).  `xt` [n_rows * d_in] receives the channel-contiguous copy
+ * of x (tfc_ir_transpose) the products read; keep it for the backward.
+ * backward: gout [n_rows, d_out]; `gt` [n_rows * d_out] is scratch for its channel-contiguous copy
+ * (gt_ready != 0: gt already holds it, gout is not read - lets two consumers of one gradient share
+ * the copy); dx (nullable) [n_rows, d_in], columns no instruction reaches left untouched; dw (nullable)
+ * [weight_numel] fully written for the blocks of the instructions.  `workspace`: optional split-K
+ * scratch of tfc_linear_workspace_floats floats for the weight gradient. */
+typedef struct tfc_linear_ins {
+    int32_t in_off, mul_in, out_off, mul_out, dim, w_off;
+    float path_weight;
+} tfc_linear_ins;
+int64_t tfc_linear_workspace_floats(const tfc_linear_ins* ins, int32_t n_ins, int64_t n_rows);
+int tfc_linear_fwd(const tfc_linear_ins* ins, int32_t n_ins, const float* x, const float* weight, int64_t n_rows,
+                   int32_t d_in, int32_t d_out, int64_t weight_numel, float* xt, float* out, tfc_stream_t stream);
+int tfc_linear_bwd(const tfc_linear_ins* ins, int32_t n_ins, const float* xt, const float* gout,
+                   const float* weight, int64_t n_rows, int32_t d_in, int32_t d_out, int64_t weight_numel,
+                   float* gt, int32_t gt_ready, float* dx, float* dw, float* workspace, int64_t workspace_floats,
+                   tfc_stream_t stream);
+
 /* Channel-contiguous copy of feature rows, for the operands of the dense contractions above:
  * e3nn stores a block as [mul][2l+1] (eigenn feature layout, see the conventions at the top), which
  * gives the contraction index u of o3.Linear / FullyConnectedTensorProduct the stride 2l+1; block b

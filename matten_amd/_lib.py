@@ -71,6 +71,18 @@ class IrBlock(C.Structure):
     _fields_ = [("off", C.c_int32), ("mul", C.c_int32), ("dim", C.c_int32)]
 
 
+class LinearIns(C.Structure):
+    _fields_ = [
+        ("in_off", C.c_int32),
+        ("mul_in", C.c_int32),
+        ("out_off", C.c_int32),
+        ("mul_out", C.c_int32),
+        ("dim", C.c_int32),
+        ("w_off", C.c_int32),
+        ("path_weight", C.c_float),
+    ]
+
+
 class GateSeg(C.Structure):
     _fields_ = [
         ("in_off", C.c_int32),
@@ -119,6 +131,12 @@ SIGNATURES = {
     "tfc_gemm_group": (C.c_int, [C.POINTER(GemmDesc), _I32, _P]),
     "tfc_gemm_workspace_floats": (_I64, [_I64, _I64, _I64]),
     "tfc_radial_mlp_fwd": (C.c_int, [_P, _I64, _I32, C.POINTER(_I32), C.POINTER(_P), _F, C.POINTER(_P), _P, _P]),
+    "tfc_radial_mlp_bwd_workspace_floats": (_I64, [_I64, _I32, C.POINTER(_I32)]),
+    "tfc_radial_mlp_bwd": (C.c_int, [_P, _I64, _I32, C.POINTER(_I32), C.POINTER(_P), _F, C.POINTER(_P), _P, C.POINTER(_P), _P,
+                                     C.POINTER(_P), _P, _I64, _P]),
+    "tfc_linear_workspace_floats": (_I64, [C.POINTER(LinearIns), _I32, _I64]),
+    "tfc_linear_fwd": (C.c_int, [C.POINTER(LinearIns), _I32, _P, _P, _I64, _I32, _I32, _I64, _P, _P, _P]),
+    "tfc_linear_bwd": (C.c_int, [C.POINTER(LinearIns), _I32, _P, _P, _P, _I64, _I32, _I32, _I64, _P, _I32, _P, _P, _P, _I64, _P]),
     "tfc_ir_transpose": (C.c_int, [_P, _I64, _I32, C.POINTER(IrBlock), _I32, _P, _P]),
     "tfc_gate_fwd": (C.c_int, [C.POINTER(GateSeg), _I32, _P, _I64, _I32, _I32, _P, _P]),
     "tfc_profile_enable": (C.c_int, [C.c_int]),

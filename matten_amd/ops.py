@@ -18,7 +18,7 @@ from typing import List, NamedTuple, Optional, Sequence, Tuple
 import torch
 
 from . import _lib
-from ._lib import GateSeg, GemmDesc, IMap, IrBlock, Path
+from ._lib import GateSeg, GemmDesc, IMap, IrBlock, LinearIns, Path
 
 __all__ = [
     "EdgeOrdering",
@@ -586,10 +586,18 @@ class LinearSpec:
     out_blocks: Tuple[Tuple[int, int, int], ...] = ()  # every (off, mul, dim) block of the output row
 
 
+@functools.lru_cache(maxsize=256)
+def _linear_ins(spec: "LinearSpec"):
+    arr = (LinearIns * len(spec.instructions))()
+    for a, (in_off, mi, out_off, mo, d, w_off, pw) in zip(arr, spec.instructions):
+        a.in_off, a.mul_in, a.out_off, a.mul_out, a.dim, a.w_off, a.path_weight = in_off, mi, out_off, mo, d, w_off, pw
+    return arr
+
+
 class _LinearFn(torch.autograd.Function):
-    """o3.Linear on channel-contiguous copies of its input and of the output gradient
-    (tfc_ir_transpose): every instruction, whatever its l, is then the same plain contraction over
-    channels, and all of them share one grouped launch."""
+    """o3.Linear through tfc_linear_fwd / tfc_linear_bwd: the products run on channel-contiguous copies
+    of the input and of the output gradient, every instruction, whatever its l, being the same plain
+    contraction over channels, all of them in one grouped launch."""
 
     @staticmethod
     def forward(ctx, x, weight, spec: LinearSpec):
@@ -599,17 +607,11 @@ class _LinearFn(torch.autograd.Function):
             raise ValueError(f"linear: x{tuple(x.shape)} / weight[{weight.numel()}] do not match the irreps ({spec.d_in}, {spec.weight_numel})")
         alloc = torch.empty if spec.out_covered else torch.zeros
         out = alloc(n, spec.d_out, dtype=torch.float32, device=x.device)
-        xt = _ir_transpose(x, [(in_off, mi, d) for in_off, mi, _, _, d, _, _ in spec.instructions])
-
-        def fwd(in_off, mi, out_off, mo, d, w_off, pw):
-            return lambda acc: _desc(
-                n * d, mo, mi, _p(xt, in_off * n), _p(weight, w_off), _p(out, out_off),
-                a1_r=_imap(1, d, mi, 0, n * mi), a1_k=_lin(1), b_k=_lin(mo), b_j=_lin(1),
-                c_r=_imap(1, d, spec.d_out, 0, 1), c_j=_lin(d), alpha=pw, accumulate=acc,
-                tag=b"gemm_linear_fwd",
-            )
-
-        _gemm_waves([(ins[2], fwd(*ins)) for ins in spec.instructions])
+        xt = torch.empty(max(n * spec.d_in, 1), dtype=torch.float32, device=x.device)
+        if spec.instructions:
+            ins = _linear_ins(spec)
+            _lib.check(_lib.lib().tfc_linear_fwd(ins, len(ins), _ptr(x), _ptr(weight), n, spec.d_in, spec.d_out, spec.weight_numel,
+                                                 _ptr(xt), _ptr(out), _stream()))
         ctx.save_for_backward(xt, weight)
         ctx.spec, ctx.n = spec, n
         return out
@@ -620,32 +622,21 @@ class _LinearFn(torch.autograd.Function):
         spec, n = ctx.spec, ctx.n
         g = _f32(g, "grad_output")
         dx = dw = None
+        if ctx.needs_input_grad[0]:
+            dx = (torch.empty if spec.in_covered else torch.zeros)(n, spec.d_in, dtype=torch.float32, device=g.device)
+        if ctx.needs_input_grad[1]:
+            dw = torch.empty_like(weight)
+        if not spec.instructions:
+            return dx, (dw.zero_() if dw is not None else None), None
         # (all blocks of the row, not only the ones reached: the copy is then shared with the other
         # consumer of the same gradient, see _ir_transpose)
         gt = _ir_transpose(g, spec.out_blocks or [(out_off, mo, d) for _, _, out_off, mo, d, _, _ in spec.instructions])
-        if ctx.needs_input_grad[0]:
-            alloc = torch.empty if spec.in_covered else torch.zeros
-            dx = alloc(n, spec.d_in, dtype=torch.float32, device=g.device)
-
-            def bdx(in_off, mi, out_off, mo, d, w_off, pw):
-                return lambda acc: _desc(
-                    n * d, mi, mo, _p(gt, out_off * n), _p(weight, w_off), _p(dx, in_off),
-                    a1_r=_imap(1, d, mo, 0, n * mo), a1_k=_lin(1), b_k=_lin(1), b_j=_lin(mo),
-                    c_r=_imap(1, d, spec.d_in, 0, 1), c_j=_lin(d), alpha=pw, accumulate=acc,
-                    tag=b"gemm_linear_dx",
-                )
-
-            _gemm_waves([(ins[0], bdx(*ins)) for ins in spec.instructions])
-        if ctx.needs_input_grad[1]:
-            dw = torch.empty_like(weight)
-            _gemm_group([
-                _desc(
-                    mi, mo, n * d, _p(xt, in_off * n), _p(gt, out_off * n), _p(dw, w_off),
-                    a1_r=_lin(1), a1_k=_imap(1, d, mi, 0, n * mi), b_k=_imap(1, d, mo, 0, n * mo), b_j=_lin(1),
-                    c_r=_lin(mo), c_j=_lin(1), alpha=pw, tag=b"gemm_linear_dw",
-                )
-                for in_off, mi, out_off, mo, d, w_off, pw in spec.instructions
-            ])
+        ins = _linear_ins(spec)
+        L = _lib.lib()
+        need = int(L.tfc_linear_workspace_floats(ins, len(ins), n)) if dw is not None else 0
+        ws = _gemm_workspace(need) if need > 0 else None
+        _lib.check(L.tfc_linear_bwd(ins, len(ins), _ptr(xt), None, _ptr(weight), n, spec.d_in, spec.d_out, spec.weight_numel,
+                                    _ptr(gt), 1, _ptr(dx), _ptr(dw), _ptr(ws), ws.numel() if ws is not None else 0, _stream()))
         return dx, dw, None
 
 
@@ -695,40 +686,25 @@ class _RadialMlpFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g):
-        L = ctx.n_layers
-        hs, ws = ctx.saved_tensors[:L], ctx.saved_tensors[L:]
+        nl = ctx.n_layers
+        hs, ws = ctx.saved_tensors[:nl], ctx.saved_tensors[nl:]  # hs[0] = x, hs[i] = output of layer i-1
         g = _f32(g, "grad_output")
         E = g.shape[0]
-        dws: List[Optional[torch.Tensor]] = [None] * L
-        dw_descs = []
-        keep = []  # gradients the deferred weight-gradient launch still reads
-        for i in range(L - 1, -1, -1):
-            w, h = ws[i], hs[i]
-            hin, hout = w.shape
-            alpha = 1.0 / math.sqrt(hin)
-            if ctx.needs_input_grad[2 + i]:
-                dw = torch.empty_like(w)
-                dw_descs.append(_desc(
-                    hin, hout, E, _p(h), _p(g), _p(dw), a1_r=_lin(1), a1_k=_lin(hin), b_k=_lin(hout), b_j=_lin(1),
-                    c_r=_lin(hout), c_j=_lin(1), alpha=alpha, tag=b"gemm_mlp_dw",
-                ))
-                keep.append(g)
-                dws[i] = dw
-            if i > 0 or ctx.needs_input_grad[0]:
-                dh = torch.empty(E, hin, dtype=torch.float32, device=g.device)
-                _gemm(
-                    E, hin, hout, _p(g), _p(w), _p(dh), a1_r=_lin(hout), a1_k=_lin(1), b_k=_lin(1), b_j=_lin(hout),
-                    c_r=_lin(hin), c_j=_lin(1), alpha=alpha,
-                    epilogue=_lib.EPI_SSP_GRAD if i > 0 else _lib.EPI_NONE, aux=_p(h) if i > 0 else None,
-                    act_cst=ctx.act_cst, tag=b"gemm_mlp_dh",
-                )
-                g = dh
-            else:
-                g = None
-        # all weight gradients (h_i^T g_i, K = number of edges) in one grouped launch
-        _gemm_group(dw_descs)
-        del keep
-        return (g if ctx.needs_input_grad[0] else None, None, *dws)
+        dev = g.device
+        dims = [hs[0].shape[1]] + [w.shape[1] for w in ws]
+        dws = [torch.empty_like(w) if ctx.needs_input_grad[2 + i] else None for i, w in enumerate(ws)]
+        dhid = [torch.empty(E, dims[i + 1], dtype=torch.float32, device=dev) for i in range(nl - 1)]
+        dx = torch.empty(E, dims[0], dtype=torch.float32, device=dev) if ctx.needs_input_grad[0] else None
+        L = _lib.lib()
+        c_dims = (C.c_int32 * (nl + 1))(*dims)
+        need = int(L.tfc_radial_mlp_bwd_workspace_floats(E, nl, c_dims))
+        wsp = _gemm_workspace(need) if need > 0 else None
+        vp = lambda ts: (C.c_void_p * max(len(ts), 1))(*[None if t is None else t.data_ptr() for t in ts])  # noqa: E731
+        _lib.check(L.tfc_radial_mlp_bwd(
+            _ptr(hs[0]), E, nl, c_dims, vp(ws), ctx.act_cst, vp(hs[1:]), _ptr(g), vp(dhid), _ptr(dx), vp(dws),
+            _ptr(wsp), wsp.numel() if wsp is not None else 0, _stream(),
+        ))
+        return (dx, None, *dws)
 
 
 def radial_mlp(x, weights: Sequence[torch.Tensor], act_cst: float):

@@ -652,3 +652,105 @@ def test_profile_modes(device):
     conv_only, everything = names(2), names(1)
     assert conv_only and all(nm.startswith("tfc_conv_") for nm in conv_only)
     assert conv_only < everything and "gemm_test" in everything
+
+
+def test_linear_c_entry_points(device):
+    """tfc_linear_fwd / tfc_linear_bwd called directly (as a C caller would): instructions in e3nn's order,
+    two in-blocks feeding one out-block (accumulated in separate launches), an out-block nobody writes
+    and an in-block nobody reads left untouched, gt handed over ready-made."""
+    import ctypes as C
+
+    from matten_amd import _lib, ops
+
+    L = _lib.lib()
+    n, d_in, d_out = 70, 8 + 4 + 3 * 5 + 6, 5 + 3 * 7 + 2
+    # in: 8x0e | 4x0e | 5x1o | 6x2e(unread)    out: 5x0e | 7x1o | 2x0o(unwritten)
+    spec = [(0, 8, 0, 5, 1, 0), (8, 4, 0, 5, 1, 40), (12, 5, 5, 7, 3, 60)]
+    pw = [12 ** -0.5, 12 ** -0.5, 5 ** -0.5]
+    ins = (_lib.LinearIns * 3)()
+    for a, q, p in zip(ins, spec, pw):
+        a.in_off, a.mul_in, a.out_off, a.mul_out, a.dim, a.w_off, a.path_weight = *q, p
+    wn = 40 + 20 + 35
+    g = torch.Generator().manual_seed(70)
+    x = torch.randn(n, d_in, generator=g, dtype=torch.float64)
+    w = torch.randn(wn, generator=g, dtype=torch.float64)
+    go = torch.randn(n, d_out, generator=g, dtype=torch.float64)
+
+    def ref(x, w):
+        out = torch.zeros(n, d_out, dtype=torch.float64)
+        for (io, mi, oo, mo, d, wo), p in zip(spec, pw):
+            xb = x[:, io : io + mi * d].reshape(n, mi, d)
+            W = w[wo : wo + mi * mo].reshape(mi, mo)
+            out[:, oo : oo + mo * d] += p * torch.einsum("nuk,uw->nwk", xb, W).reshape(n, mo * d)
+        return out
+
+    xr, wr = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    o_ref = ref(xr, wr)
+    gx_ref, gw_ref = torch.autograd.grad(o_ref, [xr, wr], go)
+    P, st = ops._ptr, ops._stream()
+    xd, wd, god = x.float().to(device), w.float().to(device), go.float().to(device)
+    out = torch.full((n, d_out), 7.0, device=device)
+    xt = torch.empty(n * d_in, device=device)
+    _lib.check(L.tfc_linear_fwd(ins, 3, P(xd), P(wd), n, d_in, d_out, wn, P(xt), P(out), st))
+    assert rel(out[:, :26], o_ref[:, :26]) < TOL and bool((out[:, 26:] == 7.0).all())
+    gt = torch.empty(n * d_out, device=device)
+    dx = torch.full((n, d_in), 3.0, device=device)
+    dw = torch.empty(wn, device=device)
+    need = int(L.tfc_linear_workspace_floats(ins, 3, n))
+    ws = torch.empty(max(need, 1), device=device)
+    _lib.check(L.tfc_linear_bwd(ins, 3, P(xt), P(god), P(wd), n, d_in, d_out, wn, P(gt), 0, P(dx), P(dw), P(ws), need, st))
+    assert rel(dx[:, :27], gx_ref[:, :27]) < TOL and bool((dx[:, 27:] == 3.0).all())
+    assert rel(dw, gw_ref) < TOL
+    # gt ready-made, gout not passed; only dx wanted
+    dx2 = torch.zeros(n, d_in, device=device)
+    _lib.check(L.tfc_linear_bwd(ins, 3, None, None, P(wd), n, d_in, d_out, wn, P(gt), 1, P(dx2), None, None, 0, st))
+    assert torch.equal(dx2[:, :27], dx[:, :27])
+    # argument errors: no launch
+    ins[2].out_off = 20
+    assert L.tfc_linear_fwd(ins, 3, P(xd), P(wd), n, d_in, d_out, wn, P(xt), P(out), st) < 0
+    ins[2].out_off = 5
+    assert L.tfc_linear_bwd(ins, 3, None, P(god), P(wd), n, d_in, d_out, wn, P(gt), 0, None, P(dw), None, 0, st) < 0  # dw without xt
+
+
+@pytest.mark.parametrize("dims,rows", [([8, 64, 64, 100], 333), ([6, 20, 12], 50), ([8, 40], 77)])
+def test_radial_mlp_bwd_c_entry_point(device, dims, rows):
+    """tfc_radial_mlp_bwd called directly against autograd on the oracle network; also with the input
+    gradient and one weight gradient not requested."""
+    import ctypes as C
+
+    from matten_amd import _lib, ops
+    from oracle import e3ref
+    from oracle.eigenn_ref import ssp
+
+    torch.manual_seed(71)
+    o = e3ref.FullyConnectedNet(dims, act=ssp, act_key="ssp").double()
+    nl = len(dims) - 1
+    x = torch.randn(rows, dims[0], dtype=torch.float64, requires_grad=True)
+    hs = [x]
+    for layer in o:
+        hs.append(layer(hs[-1]))
+    go = torch.randn_like(hs[-1])
+    ref = torch.autograd.grad(hs[-1], [x] + list(o.parameters()), go)
+    cst = float(o[0].act.cst) if nl > 1 else 1.0
+    L = _lib.lib()
+    dev = lambda t: t.detach().float().to(device).contiguous()  # noqa: E731
+    xd, god = dev(x), dev(go)
+    wd = [dev(p) for p in o.parameters()]
+    hid = [dev(h) for h in hs[1:-1]]
+    vp = lambda ts: (C.c_void_p * max(len(ts), 1))(*[None if t is None else t.data_ptr() for t in ts])  # noqa: E731
+    c_dims = (C.c_int32 * (nl + 1))(*dims)
+    dhid = [torch.empty(rows, d, device=device) for d in dims[1:-1]]
+    dx = torch.empty(rows, dims[0], device=device)
+    dws = [torch.empty_like(w) for w in wd]
+    need = int(L.tfc_radial_mlp_bwd_workspace_floats(rows, nl, c_dims))
+    ws = torch.empty(max(need, 1), device=device)
+    P = ops._ptr
+    _lib.check(L.tfc_radial_mlp_bwd(P(xd), rows, nl, c_dims, vp(wd), cst, vp(hid), P(god), vp(dhid), P(dx), vp(dws), P(ws), need, ops._stream()))
+    assert rel(dx, ref[0]) < TOL
+    for a, b in zip(dws, ref[1:]):
+        assert rel(a, b) < TOL
+    dws2 = [torch.empty_like(w) for w in wd]
+    dws2[0] = None
+    _lib.check(L.tfc_radial_mlp_bwd(P(xd), rows, nl, c_dims, vp(wd), cst, vp(hid), P(god), vp(dhid), None, vp(dws2), None, 0, ops._stream()))
+    for a, b in zip(dws2[1:], ref[2:]):
+        assert rel(a, b) < TOL
