@@ -268,6 +268,9 @@ def main():
                 ach2 = (fb / n_layers) / (tot2 / c2 * 1e-3) / 1e9
                 roof["fwd_kernel"] = {"achieved": ach2, "frac": ach2 / HBM_PEAK_GBS, "avg_launch_ms": tot2 / c2,
                                       "bytes_per_launch": fb / n_layers}
+                # the north star's figure: the convolution forward + backward together
+                both = (fb + bb) / n_layers / ((tot / c + tot2 / c2) * 1e-3) / 1e9
+                roof["fwd_plus_bwd"] = {"achieved": both, "frac": both / HBM_PEAK_GBS}
         cpu = None
         if world == 1 and not args.no_cpu_baseline:
             threads = min(16, os.cpu_count() or 1)
