@@ -39,6 +39,7 @@ WORKLOADS = {
 }
 R_CUT = 5.0
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec
+MFMA_F32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense fp32 matrix peak
 
 
 def conv_layer_bytes(layer, n_nodes, n_edges):
@@ -50,6 +51,29 @@ def conv_layer_bytes(layer, n_nodes, n_edges):
     b_fwd = 4 * (d_in + s + w) + 16 + 4 * d_mid / deg
     b_bwd = 4 * (d_mid + d_in + s + w) + 16 + 4 * (w + s) + 4 * d_in / deg
     return b_fwd * n_edges, b_bwd * n_edges, dict(d_in=d_in, s=s, d_mid=d_mid, w=w)
+
+
+def dense_flops(model, n_nodes, n_edges):
+    """Algorithmic flops per step of the genuinely dense pieces, forward + backward
+    (backward = input gradient + weight gradient = 2 x forward):
+    radial MLP 2 (B H + H H (n_hidden - 1) + H W) per edge; o3.Linear 2 sum mul_in mul_out (2l+1) per node."""
+    mlp = lin = 0.0
+    for layer in model.convs:
+        ws = [p for p in layer.message_fn.tp.weight_nn.parameters()]
+        mlp += 3 * 2.0 * n_edges * sum(w.shape[0] * w.shape[1] for w in ws)
+        for linear in (layer.message_fn.linear_1, layer.update_fn.linear_2):
+            lin += 3 * 2.0 * n_nodes * sum(mi * mo * d for _, mi, _, mo, d, _, _ in linear.spec.instructions)
+    return mlp, lin
+
+
+def mfma_roofline(kern, flops, tags):
+    """flops / (time of the launches booked under `tags` in the per-kernel breakdown pass)."""
+    ms = sum(kern[t]["launches_per_step"] * kern[t]["avg_ms"] for t in tags if t in kern)
+    if ms <= 0:
+        return None
+    ach = flops / (ms * 1e-3) / 1e12
+    return {"bound": "mfma", "achieved": ach, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / MFMA_F32_PEAK_TFLOPS,
+            "flops_per_step": flops, "ms_per_step": ms, "kernels": [t for t in tags if t in kern]}
 
 
 def pmc_traffic(workload):
@@ -271,6 +295,11 @@ def main():
                 # the north star's figure: the convolution forward + backward together
                 both = (fb + bb) / n_layers / ((tot / c + tot2 / c2) * 1e-3) / 1e9
                 roof["fwd_plus_bwd"] = {"achieved": both, "frac": both / HBM_PEAK_GBS}
+        mlp_flops, lin_flops = dense_flops(model, n_nodes, n_edges)
+        dense = {
+            "radial_mlp": mfma_roofline(kern, mlp_flops, ["mlp_fused_fwd", "gemm_mlp_fwd", "gemm_mlp_dh", "gemm_mlp_dw"]),
+            "o3_linear": mfma_roofline(kern, lin_flops, ["gemm_linear_fwd", "gemm_linear_dx", "gemm_linear_dw"]),
+        }
         cpu = None
         if world == 1 and not args.no_cpu_baseline:
             threads = min(16, os.cpu_count() or 1)
@@ -303,6 +332,7 @@ def main():
                 "layer_shapes": shapes,
             },
             "roofline": roof,
+            "mfma_roofline": dense,
             "cpu_baseline": cpu,
             "kernels": kern,
         }

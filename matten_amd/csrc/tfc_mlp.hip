@@ -13,13 +13,20 @@
 // layer, every input / hidden width <= 64, output width a multiple of 4.
 #include "tfc_common.h"
 
+#include <cstdlib>
+
 namespace {
 
 typedef float floatx16 __attribute__((ext_vector_type(16)));
 
 constexpr int MAXL = 6;   // layers
-constexpr int RB = 128;   // edges per workgroup
-constexpr int SA = RB + 4;  // LDS row stride of the activation tile [k][row]
+// NA = accumulator tiles (32 rows each) per wave: the workgroup owns RB = 64 * NA edges.  NA = 2
+// halves the number of times W_L is streamed from L2; NA = 1 doubles the number of workgroups and
+// lets three of them share a CU, which is what fills the chip when E / 128 is only a few hundred.
+template <int NA> struct Tile {
+    static constexpr int RB = 64 * NA;   // edges per workgroup
+    static constexpr int SA = RB + 4;    // LDS row stride of the activation tile [k][row]
+};
 constexpr int SB = 64 + 4;  // LDS row stride of a weight tile [k][col]
 
 struct MlpArgs {
@@ -33,8 +40,12 @@ struct MlpArgs {
     float act_cst;
 };
 
+// cst * (softplus(v) - ln 2), softplus(v) = max(v, 0) + log(1 + exp(-|v|)) on the hardware exp2 / log2
+// units: absolute error ~1e-7 (the argument of the log lies in (1, 2]), against ~100 instructions
+// per element for the libm log1pf(expf(v)) this replaces
 __device__ __forceinline__ float ssp_act(float v, float cst) {
-    const float sp = v > 20.f ? v : log1pf(expf(v));
+    const float t = __expf(-fabsf(v));
+    const float sp = fmaxf(v, 0.f) + __logf(1.f + t);
     return cst * (sp - 0.69314718055994530942f);
 }
 
@@ -61,7 +72,9 @@ __device__ __forceinline__ void stage_weights(const float* __restrict__ W, int K
     }
 }
 
-__global__ __launch_bounds__(256, 2) void tfc_radial_mlp_fwd_kernel(const MlpArgs a) {
+template <int NA>
+__global__ __launch_bounds__(256, (NA == 1 ? 3 : 2)) void tfc_radial_mlp_fwd_kernel(const MlpArgs a) {
+    constexpr int RB = Tile<NA>::RB, SA = Tile<NA>::SA;
     __shared__ __attribute__((aligned(16))) float act[64 * SA];     // current activations, [k][row]
     __shared__ __attribute__((aligned(16))) float wt[2][64 * SB];   // weight tiles, [k][col]
 
@@ -80,33 +93,35 @@ __global__ __launch_bounds__(256, 2) void tfc_radial_mlp_fwd_kernel(const MlpArg
             act[k * SA + row] = k < d0 ? a.x[r * d0 + k] : 0.f;
         }
     }
+    const bool full_rows = r0 + RB <= a.n_rows;  // no row of this workgroup lies past the end
     // hidden layers
     for (int l = 0; l + 1 < a.n_layers; ++l) {
         const int din = a.dims[l], dout = a.dims[l + 1];
         stage_weights(a.w[l], din, dout, 0, dout, wt[0], t);
         __syncthreads();
-        floatx16 acc[2];
+        floatx16 acc[NA];
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < NA; ++i)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
         const int kp = (din + 1) >> 1;  // k pairs (an odd width reads one zero row of padding)
         for (int s = 0; s < kp; ++s) {
             const float b = wt[0][(2 * s + half) * SB + wn * 32 + l31];
-            const float a0 = act[(2 * s + half) * SA + wm * 64 + l31];
-            const float a1 = act[(2 * s + half) * SA + wm * 64 + 32 + l31];
-            acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b, acc[0], 0, 0, 0);
-            acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b, acc[1], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < NA; ++i) {
+                const float av = act[(2 * s + half) * SA + wm * 32 * NA + 32 * i + l31];
+                acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b, acc[i], 0, 0, 0);
+            }
         }
         __syncthreads();  // every wave has read the old activations
         const float alpha = 1.0f / sqrtf((float)din);
         const int c = wn * 32 + l31;
         float* hid = a.hidden[l];
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
+        for (int i = 0; i < NA; ++i) {
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                const int row = wm * 64 + i * 32 + 8 * g + 4 * half;
+                const int row = wm * 32 * NA + i * 32 + 8 * g + 4 * half;
                 float4 v;
                 v.x = c < dout ? ssp_act(alpha * acc[i][4 * g + 0], a.act_cst) : 0.f;
                 v.y = c < dout ? ssp_act(alpha * acc[i][4 * g + 1], a.act_cst) : 0.f;
@@ -114,10 +129,18 @@ __global__ __launch_bounds__(256, 2) void tfc_radial_mlp_fwd_kernel(const MlpArg
                 v.w = c < dout ? ssp_act(alpha * acc[i][4 * g + 3], a.act_cst) : 0.f;
                 *reinterpret_cast<float4*>(&act[c * SA + row]) = v;
                 if (c < dout) {
-                    if (r0 + row + 0 < a.n_rows) hid[(r0 + row + 0) * dout + c] = v.x;
-                    if (r0 + row + 1 < a.n_rows) hid[(r0 + row + 1) * dout + c] = v.y;
-                    if (r0 + row + 2 < a.n_rows) hid[(r0 + row + 2) * dout + c] = v.z;
-                    if (r0 + row + 3 < a.n_rows) hid[(r0 + row + 3) * dout + c] = v.w;
+                    float* __restrict__ hp = hid + (r0 + row) * dout + c;
+                    if (full_rows) {
+                        hp[0] = v.x;
+                        hp[dout] = v.y;
+                        hp[2 * dout] = v.z;
+                        hp[3 * dout] = v.w;
+                    } else {
+                        if (r0 + row + 0 < a.n_rows) hp[0] = v.x;
+                        if (r0 + row + 1 < a.n_rows) hp[dout] = v.y;
+                        if (r0 + row + 2 < a.n_rows) hp[2 * dout] = v.z;
+                        if (r0 + row + 3 < a.n_rows) hp[3 * dout] = v.w;
+                    }
                 }
             }
         }
@@ -132,6 +155,13 @@ __global__ __launch_bounds__(256, 2) void tfc_radial_mlp_fwd_kernel(const MlpArg
         const int kp = (din + 1) >> 1;
         const int nsteps = (W + 63) / 64;
         stage_weights(wl, din, W, 0, W, wt[0], t);
+        const bool full = full_rows;
+        unsigned ooff[NA][16];
+#pragma unroll
+        for (int i = 0; i < NA; ++i)
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg)
+                ooff[i][reg] = (unsigned)(wm * 32 * NA + i * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * half) * (unsigned)W + wn * 32 + l31;
         __syncthreads();
         for (int n = 0; n < nsteps; ++n) {
             const int cur = n & 1;
@@ -149,19 +179,40 @@ __global__ __launch_bounds__(256, 2) void tfc_radial_mlp_fwd_kernel(const MlpArg
                     pre[q] = v;
                 }
             }
-            floatx16 acc[2];
+            floatx16 acc[NA];
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+            for (int i = 0; i < NA; ++i)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
             const float* Bs = wt[cur];
-#pragma unroll 8
-            for (int s = 0; s < kp; ++s) {
-                const float b = Bs[(2 * s + half) * SB + wn * 32 + l31];
-                const float a0 = act[(2 * s + half) * SA + wm * 64 + l31];
-                const float a1 = act[(2 * s + half) * SA + wm * 64 + 32 + l31];
-                acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b, acc[0], 0, 0, 0);
-                acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b, acc[1], 0, 0, 0);
+            // K = 64 (the usual hidden width): all operands of the tile are fetched from LDS into
+            // registers first and the 64 matrix instructions then run back to back, waiting only for
+            // the operand they are about to use (a rolled loop waits out the LDS latency before every
+            // pair of them: the matrix core then idles more than half of the time)
+            if (kp == 32) {
+                float bv[32], av[NA][32];
+#pragma unroll
+                for (int s = 0; s < 32; ++s) {
+                    bv[s] = Bs[(2 * s + half) * SB + wn * 32 + l31];
+#pragma unroll
+                    for (int i = 0; i < NA; ++i) av[i][s] = act[(2 * s + half) * SA + wm * 32 * NA + 32 * i + l31];
+                }
+                __builtin_amdgcn_sched_barrier(0);  // keep the scheduler from sinking the reads back to their uses
+#pragma unroll
+                for (int s = 0; s < 32; ++s) {
+#pragma unroll
+                    for (int i = 0; i < NA; ++i)
+                        acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i][s], bv[s], acc[i], 0, 0, 0);
+                }
+            } else {
+                for (int s = 0; s < kp; ++s) {
+                    const float b = Bs[(2 * s + half) * SB + wn * 32 + l31];
+#pragma unroll
+                    for (int i = 0; i < NA; ++i) {
+                        const float av = act[(2 * s + half) * SA + wm * 32 * NA + 32 * i + l31];
+                        acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b, acc[i], 0, 0, 0);
+                    }
+                }
             }
             if (more) {
 #pragma unroll
@@ -172,13 +223,22 @@ __global__ __launch_bounds__(256, 2) void tfc_radial_mlp_fwd_kernel(const MlpArg
             }
             const int c = n * 64 + wn * 32 + l31;
             if (c < W) {
+                // uniform base of the tile + per-lane 32-bit offsets that do not change from tile to tile
+                float* __restrict__ ob = a.out + r0 * W + n * 64;
+                if (full) {
 #pragma unroll
-                for (int i = 0; i < 2; ++i)
+                    for (int i = 0; i < NA; ++i)
 #pragma unroll
-                    for (int reg = 0; reg < 16; ++reg) {
-                        const long row = r0 + wm * 64 + i * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * half;
-                        if (row < a.n_rows) a.out[row * W + c] = alpha * acc[i][reg];
-                    }
+                        for (int reg = 0; reg < 16; ++reg) ob[ooff[i][reg]] = alpha * acc[i][reg];
+                } else {
+#pragma unroll
+                    for (int i = 0; i < NA; ++i)
+#pragma unroll
+                        for (int reg = 0; reg < 16; ++reg) {
+                            const long row = r0 + wm * 32 * NA + i * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * half;
+                            if (row < a.n_rows) ob[ooff[i][reg]] = alpha * acc[i][reg];
+                        }
+                }
             }
             __syncthreads();
         }
@@ -223,10 +283,20 @@ extern "C" int tfc_radial_mlp_fwd(const float* x, int64_t n_rows, int32_t n_laye
             a.hidden[i] = hidden[i];
         }
     }
-    const long nb = (n_rows + RB - 1) / RB;
+    // 64- or 128-edge workgroups: whichever needs fewer rounds x rows on 256 CUs (3 resp. 2 workgroups
+    // resident per CU); a tie goes to 128, which streams W_L half as often
+    static const int forced = getenv("TFC_MLP_RB") ? atoi(getenv("TFC_MLP_RB")) : 0;
+    const long nb128 = (n_rows + 127) / 128, nb64 = (n_rows + 63) / 64;
+    const long cost128 = (nb128 + 511) / 512 * 128, cost64 = (nb64 + 767) / 768 * 64;
+    const bool small = forced ? forced == 64 : cost64 < cost128;
+    const int rb = small ? 64 : 128;
+    const long nb = (n_rows + rb - 1) / rb;
     TFC_REQUIRE(nb < (1LL << 31), TFC_EUNSUPPORTED, "tfc_radial_mlp_fwd: grid too large");
     TfcProfScope prof("mlp_fused_fwd", stream);
-    tfc_radial_mlp_fwd_kernel<<<(unsigned)nb, 256, 0, stream>>>(a);
+    if (small)
+        tfc_radial_mlp_fwd_kernel<1><<<(unsigned)nb, 256, 0, stream>>>(a);
+    else
+        tfc_radial_mlp_fwd_kernel<2><<<(unsigned)nb, 256, 0, stream>>>(a);
     TFC_LAUNCH_CHECK("tfc_radial_mlp_fwd_kernel");
     return TFC_OK;
 }
