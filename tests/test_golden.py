@@ -57,3 +57,59 @@ def test_hip_reproduces_golden(device, name):
     model = Stack("hip", CONFIGS[name])
     model.load_state_dict(ref.state_dict(), strict=True)
     compare(run_stack(model, batch, str(device), torch.float32), z, 1e-5)
+
+
+# ------------------------------------------------------------------ legacy PointConv (pointconv_legacy.npz)
+def _pointconv(impl):
+    from tests.golden import make_pointconv_golden as G
+
+    if impl == "oracle":
+        from oracle import eigenn_ref as M
+    else:
+        import matten_amd.nn as M
+    torch.manual_seed(35)
+    return M.PointConv(G.IRREPS_IN, G.IRREPS_OUT, **G.KWARGS), G
+
+
+def _compare_pointconv(res, tol):
+    z = np.load(os.path.join(HERE, "golden", "pointconv_legacy.npz"), allow_pickle=False)
+    keys = [k for k in z.files if k != "weight_guard"]
+    assert sorted(keys) == sorted(res)
+    for k in keys:
+        assert rel_err(res[k], torch.from_numpy(z[k])) <= tol, k
+    return z
+
+
+def test_oracle_reproduces_pointconv_golden():
+    layer, G = _pointconv("oracle")
+    res = G.run(layer.double(), *G.inputs())
+    z = _compare_pointconv(res, 1e-12)
+    assert np.allclose(layer.linear_1.weight.detach()[:8].numpy(), z["weight_guard"])
+
+
+@pytest.mark.gpu
+def test_hip_reproduces_pointconv_golden(device):
+    """The legacy single-module layer of the reference's constructor test, through the C ABI."""
+    ref, G = _pointconv("oracle")
+    layer, _ = _pointconv("hip")
+    layer.load_state_dict(ref.state_dict(), strict=True)
+    layer = layer.to(device)
+    args = [t.to(device) if not t.is_floating_point() else t.float().to(device) for t in G.inputs()]
+    _compare_pointconv(G.run(layer, *args), 1e-5)
+
+
+@pytest.mark.gpu
+def test_hip_pointconv_refuses_what_the_kernels_do_not_cover(device):
+    """The reference's literal test irreps (edge attributes of multiplicity 4, non-scalar node
+    attributes) construct, as its test requires, and raise NotImplementedError when called."""
+    import matten_amd.nn as H
+
+    conv = H.PointConv(
+        irreps_in={"node_features": "4x1e+2x0e", "node_attrs": "4x1e+2x0e", "edge_attrs": "4x1e+2x0e", "edge_embedding": "4x0e"},
+        irreps_out={"node_features": "8x1e+4x0e"},
+    ).to(device)
+    data = {"node_features": torch.randn(5, 14, device=device), "node_attrs": torch.randn(5, 14, device=device),
+            "edge_attrs": torch.randn(9, 14, device=device), "edge_embedding": torch.randn(9, 4, device=device),
+            "edge_index": torch.randint(0, 5, (2, 9), device=device)}
+    with pytest.raises(NotImplementedError):
+        conv(data)
