@@ -307,6 +307,32 @@ int tfc_linear_bwd(const tfc_linear_ins* ins, int32_t n_ins, const float* xt, co
                    float* gt, int32_t gt_ready, float* dx, float* dw, float* workspace, int64_t workspace_floats,
                    tfc_stream_t stream);
 
+/* o3.FullyConnectedTensorProduct(in1, in2, out) with a SCALAR second input and shared internal
+ * weights: the self connection (eigenn/nn/point_conv.py:159-164, called at :185-188).  One
+ * tfc_fctp_ins per e3nn instruction (i1, i2, i_out) with ir_out = ir1 (l2 = 0), in e3nn's order:
+ *     out[n, out_off + w*dim + k] (+)= alpha * sum_{u,v} W[w_off + (u*mul_v + v)*mul_w + w]
+ *                                                * x[n, x_off + u*dim + k] * a[n, a_off + v]
+ * forward: accumulate != 0 adds to what `out` holds (e.g. linear_2's result, saving the separate
+ * add of point_conv.py:188); otherwise columns no instruction writes are left untouched.
+ * backward: gout/gt/gt_ready as for tfc_linear_bwd; dx [n_rows, d_x], dw [weight_numel], da
+ * [n_rows, d_a] are each optional (null: not computed).  da needs two scratch buffers: xt
+ * [n_rows * d_x] (channel-contiguous copy of x) and da_part [n_ins * n_rows * d_a] (one partial
+ * per instruction, added in instruction order: deterministic).  `workspace`: optional split-K
+ * scratch of tfc_fctp_workspace_floats floats.  The low-rank route of DESIGN.md §4 (attributes that
+ * are copies of few rows) is these same calls on the re-associated operands. */
+typedef struct tfc_fctp_ins {
+    int32_t x_off, mul_u, a_off, mul_v, out_off, mul_w, dim, w_off;
+    float alpha;
+} tfc_fctp_ins;
+int64_t tfc_fctp_workspace_floats(const tfc_fctp_ins* ins, int32_t n_ins, int64_t n_rows);
+int tfc_fctp_fwd(const tfc_fctp_ins* ins, int32_t n_ins, const float* x, const float* a, const float* weight,
+                 int64_t n_rows, int32_t d_x, int32_t d_a, int32_t d_out, int64_t weight_numel, int32_t accumulate,
+                 float* out, float* workspace, int64_t workspace_floats, tfc_stream_t stream);
+int tfc_fctp_bwd(const tfc_fctp_ins* ins, int32_t n_ins, const float* x, const float* a, const float* weight,
+                 const float* gout, int64_t n_rows, int32_t d_x, int32_t d_a, int32_t d_out, int64_t weight_numel,
+                 float* gt, int32_t gt_ready, float* dx, float* dw, float* da, float* xt, float* da_part,
+                 float* workspace, int64_t workspace_floats, tfc_stream_t stream);
+
 /* Channel-contiguous copy of feature rows, for the operands of the dense contractions above:
  * e3nn stores a block as [mul][2l+1] (eigenn feature layout, see the conventions at the top), which
  * gives the contraction index u of o3.Linear / FullyConnectedTensorProduct the stride 2l+1; block b

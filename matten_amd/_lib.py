@@ -83,6 +83,10 @@ class LinearIns(C.Structure):
     ]
 
 
+class FctpIns(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("x_off", "mul_u", "a_off", "mul_v", "out_off", "mul_w", "dim", "w_off")] + [("alpha", C.c_float)]
+
+
 class GateSeg(C.Structure):
     _fields_ = [
         ("in_off", C.c_int32),
@@ -137,6 +141,10 @@ SIGNATURES = {
     "tfc_linear_workspace_floats": (_I64, [C.POINTER(LinearIns), _I32, _I64]),
     "tfc_linear_fwd": (C.c_int, [C.POINTER(LinearIns), _I32, _P, _P, _I64, _I32, _I32, _I64, _P, _P, _P]),
     "tfc_linear_bwd": (C.c_int, [C.POINTER(LinearIns), _I32, _P, _P, _P, _I64, _I32, _I32, _I64, _P, _I32, _P, _P, _P, _I64, _P]),
+    "tfc_fctp_workspace_floats": (_I64, [C.POINTER(FctpIns), _I32, _I64]),
+    "tfc_fctp_fwd": (C.c_int, [C.POINTER(FctpIns), _I32, _P, _P, _P, _I64, _I32, _I32, _I32, _I64, _I32, _P, _P, _I64, _P]),
+    "tfc_fctp_bwd": (C.c_int, [C.POINTER(FctpIns), _I32, _P, _P, _P, _P, _I64, _I32, _I32, _I32, _I64, _P, _I32, _P, _P, _P, _P, _P,
+                               _P, _I64, _P]),
     "tfc_ir_transpose": (C.c_int, [_P, _I64, _I32, C.POINTER(IrBlock), _I32, _P, _P]),
     "tfc_gate_fwd": (C.c_int, [C.POINTER(GateSeg), _I32, _P, _I64, _I32, _I32, _P, _P]),
     "tfc_profile_enable": (C.c_int, [C.c_int]),

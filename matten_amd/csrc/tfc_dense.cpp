@@ -10,6 +10,8 @@
 #include <map>
 #include <vector>
 
+int tfc_sum_parts(const float* part, int n_parts, long numel, float* out, hipStream_t stream);  // tfc_layout.hip
+
 namespace {
 
 tfc_imap imap(int d1, int d2, long s0, long s1, long s2) { return tfc_imap{d1, d2, s0, s1, s2}; }
@@ -236,5 +238,196 @@ extern "C" int tfc_radial_mlp_bwd(const float* x, int64_t n_rows, int32_t n_laye
     }
     // all weight gradients (h_i^T g_{i+1}, K = rows) in one grouped launch
     if (!dws.empty()) return tfc_gemm_group(dws.data(), (int)dws.size(), stream);
+    return TFC_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// FullyConnectedTensorProduct with a scalar second input (the self connection,
+// eigenn/nn/point_conv.py:159-164,185-188).
+// ---------------------------------------------------------------------------------------------
+namespace {
+
+int check_fctp(const tfc_fctp_ins* ins, int n_ins, int d_x, int d_a, int d_out, long w_numel, const char* who) {
+    TFC_REQUIRE(ins && n_ins > 0 && n_ins <= 4096, TFC_EINVAL, "%s: %d instructions", who, n_ins);
+    for (int i = 0; i < n_ins; ++i) {
+        const tfc_fctp_ins& q = ins[i];
+        TFC_REQUIRE(q.mul_u > 0 && q.mul_v > 0 && q.mul_w > 0 && q.dim > 0, TFC_EINVAL, "%s: instruction %d is empty", who, i);
+        TFC_REQUIRE(q.x_off >= 0 && (long)q.x_off + (long)q.mul_u * q.dim <= d_x, TFC_EINVAL,
+                    "%s: instruction %d reads outside the first input row", who, i);
+        TFC_REQUIRE(q.a_off >= 0 && q.a_off + q.mul_v <= d_a, TFC_EINVAL,
+                    "%s: instruction %d reads outside the second input row", who, i);
+        TFC_REQUIRE(q.out_off >= 0 && (long)q.out_off + (long)q.mul_w * q.dim <= d_out, TFC_EINVAL,
+                    "%s: instruction %d writes outside the output row", who, i);
+        TFC_REQUIRE(q.w_off >= 0 && (long)q.w_off + (long)q.mul_u * q.mul_v * q.mul_w <= w_numel, TFC_EINVAL,
+                    "%s: instruction %d reads outside the weights", who, i);
+    }
+    return TFC_OK;
+}
+
+template <class KeyOf, class Make>
+int run_fctp_waves(const tfc_fctp_ins* ins, int n_ins, KeyOf key_of, Make make, float* ws, long ws_floats,
+                   hipStream_t stream) {
+    std::map<int, int> seen;
+    std::vector<std::vector<tfc_gemm_desc>> waves;
+    for (int i = 0; i < n_ins; ++i) {
+        const int w = seen[key_of(ins[i])]++;
+        if ((int)waves.size() <= w) waves.emplace_back();
+        tfc_gemm_desc d = make(ins[i], w > 0);
+        d.workspace = ws;
+        d.workspace_floats = ws ? ws_floats : 0;
+        waves[w].push_back(d);
+    }
+    for (auto& g : waves) {
+        int rc = tfc_gemm_group(g.data(), (int)g.size(), (tfc_stream_t)stream);
+        if (rc != TFC_OK) return rc;
+    }
+    return TFC_OK;
+}
+
+}  // namespace
+
+extern "C" int tfc_fctp_fwd(const tfc_fctp_ins* ins, int32_t n_ins, const float* x, const float* a,
+                            const float* weight, int64_t n_rows, int32_t d_x, int32_t d_a, int32_t d_out,
+                            int64_t weight_numel, int32_t accumulate, float* out, float* workspace,
+                            int64_t workspace_floats, tfc_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    TFC_REQUIRE(n_rows >= 0 && d_x > 0 && d_a > 0 && d_out > 0, TFC_EINVAL, "tfc_fctp_fwd: bad size");
+    int rc = check_fctp(ins, n_ins, d_x, d_a, d_out, weight_numel, "tfc_fctp_fwd");
+    if (rc != TFC_OK) return rc;
+    if (n_rows == 0) return TFC_OK;
+    TFC_REQUIRE(x && a && weight && out, TFC_EINVAL, "tfc_fctp_fwd: null tensor");
+    const long n = n_rows;
+    // out[(n,k), w] (+)= alpha sum_{(u,v)} x[n,u,k] a[n,v] W[(u,v), w]; the operand x (x) a is formed while staging
+    return run_fctp_waves(
+        ins, n_ins, [](const tfc_fctp_ins& q) { return q.out_off; },
+        [&](const tfc_fctp_ins& q, bool acc) {
+            tfc_gemm_desc d = desc(n * q.dim, q.mul_w, (long)q.mul_u * q.mul_v, x + q.x_off, weight + q.w_off,
+                                   out + q.out_off, imap(1, q.dim, d_x, 0, 1), imap(1, q.mul_v, q.dim, 0, 0),
+                                   lin(q.mul_w), lin(1), imap(1, q.dim, d_out, 0, 1), lin(q.dim), q.alpha,
+                                   acc || accumulate, "gemm_fctp_fwd");
+            d.a2 = a + q.a_off;
+            d.a2_r = imap(1, q.dim, d_a, 0, 0);
+            d.a2_k = imap(1, q.mul_v, 0, 0, 1);
+            return d;
+        },
+        workspace, workspace_floats, stream);
+}
+
+extern "C" int64_t tfc_fctp_workspace_floats(const tfc_fctp_ins* ins, int32_t n_ins, int64_t n_rows) {
+    if (!ins || n_ins <= 0 || n_rows < 0) return -1;
+    // each of the four products is one grouped launch (needs add up); they follow one another
+    int64_t fw = 0, dx = 0, dw = 0, da = 0;
+    for (int i = 0; i < n_ins; ++i) {
+        const tfc_fctp_ins& q = ins[i];
+        fw += tfc_gemm_workspace_floats(n_rows * q.dim, q.mul_w, (long)q.mul_u * q.mul_v);
+        dx += tfc_gemm_workspace_floats(n_rows * q.dim, q.mul_u, (long)q.mul_v * q.mul_w);
+        dw += tfc_gemm_workspace_floats((long)q.mul_u * q.mul_v, q.mul_w, n_rows * q.dim);
+        da += tfc_gemm_workspace_floats(n_rows, q.mul_v, (long)q.dim * q.mul_u * q.mul_w);
+    }
+    return std::max(std::max(fw, dx), std::max(dw, da));
+}
+
+extern "C" int tfc_fctp_bwd(const tfc_fctp_ins* ins, int32_t n_ins, const float* x, const float* a,
+                            const float* weight, const float* gout, int64_t n_rows, int32_t d_x, int32_t d_a,
+                            int32_t d_out, int64_t weight_numel, float* gt, int32_t gt_ready, float* dx, float* dw,
+                            float* da, float* xt, float* da_part, float* workspace, int64_t workspace_floats,
+                            tfc_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    TFC_REQUIRE(n_rows >= 0 && d_x > 0 && d_a > 0 && d_out > 0, TFC_EINVAL, "tfc_fctp_bwd: bad size");
+    int rc = check_fctp(ins, n_ins, d_x, d_a, d_out, weight_numel, "tfc_fctp_bwd");
+    if (rc != TFC_OK) return rc;
+    TFC_REQUIRE(gt && (gt_ready || gout), TFC_EINVAL, "tfc_fctp_bwd: null gradient");
+    TFC_REQUIRE(!da || (xt && da_part), TFC_EINVAL, "tfc_fctp_bwd: the attribute gradient needs the xt and da_part scratch");
+    const long n = n_rows;
+    if (n == 0) {
+        if (dw) TFC_HIP(hipMemsetAsync(dw, 0, sizeof(float) * (size_t)weight_numel, stream));
+        return TFC_OK;
+    }
+    TFC_REQUIRE(x && a && weight, TFC_EINVAL, "tfc_fctp_bwd: null tensor");
+    if (!gt_ready) {
+        std::vector<tfc_ir_block> blocks;
+        for (int i = 0; i < n_ins; ++i) blocks.push_back(tfc_ir_block{ins[i].out_off, ins[i].mul_w, ins[i].dim});
+        rc = transpose_blocks(gout, n, d_out, blocks, gt, stream);
+        if (rc != TFC_OK) return rc;
+    }
+    if (dx) {
+        // dx[(n,k), u] = alpha sum_{(v,w)} a[n,v] g[n,w,k] W[u,v,w]
+        rc = run_fctp_waves(
+            ins, n_ins, [](const tfc_fctp_ins& q) { return q.x_off; },
+            [&](const tfc_fctp_ins& q, bool acc) {
+                tfc_gemm_desc d = desc(n * q.dim, q.mul_u, (long)q.mul_v * q.mul_w, a + q.a_off, weight + q.w_off,
+                                       dx + q.x_off, imap(1, q.dim, d_a, 0, 0), imap(1, q.mul_w, 1, 0, 0), lin(1),
+                                       lin((long)q.mul_v * q.mul_w), imap(1, q.dim, d_x, 0, 1), lin(q.dim), q.alpha,
+                                       acc, "gemm_fctp_dx");
+                d.a2 = gt + (long)q.out_off * n;
+                d.a2_r = imap(1, q.dim, q.mul_w, 0, n * q.mul_w);
+                d.a2_k = imap(1, q.mul_w, 0, 0, 1);
+                return d;
+            },
+            workspace, workspace_floats, stream);
+        if (rc != TFC_OK) return rc;
+    }
+    if (da) {
+        // da[n, v] = alpha sum_{(k,u,w)} x[n,u,k] g[n,w,k] W[u,v,w]: every instruction writes its own partial
+        // [n_rows, d_a] in one grouped launch, the partials are then added in instruction order
+        std::vector<tfc_ir_block> blocks;
+        for (int i = 0; i < n_ins; ++i) blocks.push_back(tfc_ir_block{ins[i].x_off, ins[i].mul_u, ins[i].dim});
+        rc = transpose_blocks(x, n, d_x, blocks, xt, stream);
+        if (rc != TFC_OK) return rc;
+        TFC_HIP(hipMemsetAsync(da_part, 0, sizeof(float) * (size_t)n_ins * n * d_a, stream));
+        std::vector<tfc_gemm_desc> g;
+        for (int i = 0; i < n_ins; ++i) {
+            const tfc_fctp_ins& q = ins[i];
+            const long mu = q.mul_u, mv = q.mul_v, mw = q.mul_w;
+            float* c = da_part + (long)i * n * d_a + q.a_off;
+            tfc_gemm_desc d;
+            // the sum over the 2l+1 components folded into the operand where that was measured to pay
+            const bool fold = (q.dim == 3 || q.dim == 5) && mv <= 64 && mw % 4 == 0 && ((long)q.out_off * n) % 4 == 0 &&
+                              (n * mw) % 4 == 0 && ((uintptr_t)gt & 15) == 0;
+            if (fold) {
+                d = desc(n, mv, mu * mw, xt + (long)q.x_off * n, weight + q.w_off, c, lin(mu), imap(1, (int)mw, 1, 0, 0),
+                         imap(1, (int)mw, mv * mw, 0, 1), lin(mw), lin(d_a), lin(1), q.alpha, false, "gemm_fctp_da");
+                d.a2 = gt + (long)q.out_off * n;
+                d.a2_r = lin(mw);
+                d.a2_k = imap(1, (int)mw, 0, 0, 1);
+                d.a_rep = q.dim;
+                d.a1_rep_stride = n * mu;
+                d.a2_rep_stride = n * mw;
+            } else {
+                d = desc(n, mv, q.dim * mu * mw, xt + (long)q.x_off * n, weight + q.w_off, c, lin(mu),
+                         imap((int)mu, (int)mw, n * mu, 1, 0), imap((int)mu, (int)mw, 0, mv * mw, 1), lin(mw), lin(d_a),
+                         lin(1), q.alpha, false, "gemm_fctp_da");
+                d.a2 = gt + (long)q.out_off * n;
+                d.a2_r = lin(mw);
+                d.a2_k = imap((int)mu, (int)mw, n * mw, 0, 1);
+            }
+            d.workspace = workspace;
+            d.workspace_floats = workspace ? workspace_floats : 0;
+            g.push_back(d);
+        }
+        rc = tfc_gemm_group(g.data(), (int)g.size(), stream_);
+        if (rc != TFC_OK) return rc;
+        rc = tfc_sum_parts(da_part, n_ins, n * d_a, da, stream);
+        if (rc != TFC_OK) return rc;
+    }
+    if (dw) {
+        // dW[(u,v), w] = alpha sum_{(n,k)} x[n,u,k] a[n,v] g[n,w,k]; every instruction owns its weight block
+        std::vector<tfc_gemm_desc> g;
+        for (int i = 0; i < n_ins; ++i) {
+            const tfc_fctp_ins& q = ins[i];
+            tfc_gemm_desc d = desc((long)q.mul_u * q.mul_v, q.mul_w, n * q.dim, x + q.x_off, gt + (long)q.out_off * n,
+                                   dw + q.w_off, imap(1, q.mul_v, q.dim, 0, 0), imap(1, q.dim, d_x, 0, 1),
+                                   imap(1, q.dim, q.mul_w, 0, n * q.mul_w), lin(1), lin(q.mul_w), lin(1), q.alpha, false,
+                                   "gemm_fctp_dw");
+            d.a2 = a + q.a_off;
+            d.a2_r = imap(1, q.mul_v, 0, 0, 1);
+            d.a2_k = imap(1, q.dim, d_a, 0, 0);
+            d.workspace = workspace;
+            d.workspace_floats = workspace ? workspace_floats : 0;
+            g.push_back(d);
+        }
+        rc = tfc_gemm_group(g.data(), (int)g.size(), stream_);
+        if (rc != TFC_OK) return rc;
+    }
     return TFC_OK;
 }

@@ -41,7 +41,26 @@ __global__ __launch_bounds__(256) void tfc_ir_transpose_kernel(const Blocks bl, 
     }
 }
 
+// out[i] = sum_p part[p * numel + i], p ascending (fixed order)
+__global__ __launch_bounds__(256) void tfc_sum_parts_kernel(const float* __restrict__ part, int n_parts, long numel,
+                                                            float* __restrict__ out) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < numel; i += (long)gridDim.x * blockDim.x) {
+        float s = part[i];
+        for (int p = 1; p < n_parts; ++p) s += part[(long)p * numel + i];
+        out[i] = s;
+    }
+}
+
 }  // namespace
+
+// internal (tfc_dense.cpp): ordered sum of n_parts slabs of numel floats
+int tfc_sum_parts(const float* part, int n_parts, long numel, float* out, hipStream_t stream) {
+    if (numel <= 0 || n_parts <= 0) return TFC_OK;
+    const int grid = (int)std::min<long>((numel + 255) / 256, 4096);
+    tfc_sum_parts_kernel<<<grid, 256, 0, stream>>>(part, n_parts, numel, out);
+    TFC_LAUNCH_CHECK("tfc_sum_parts_kernel");
+    return TFC_OK;
+}
 
 extern "C" int tfc_ir_transpose(const float* x, int64_t n_rows, int32_t d_row, const tfc_ir_block* blocks,
                                 int32_t n_blocks, float* out, tfc_stream_t stream_) {

@@ -18,7 +18,7 @@ from typing import List, NamedTuple, Optional, Sequence, Tuple
 import torch
 
 from . import _lib
-from ._lib import GateSeg, GemmDesc, IMap, IrBlock, LinearIns, Path
+from ._lib import FctpIns, GateSeg, GemmDesc, IMap, IrBlock, LinearIns, Path
 
 __all__ = [
     "EdgeOrdering",
@@ -730,85 +730,48 @@ class FctpSpec:
     out_blocks: Tuple[Tuple[int, int, int], ...] = ()  # every (off, mul, dim) block of the output row
 
 
+@functools.lru_cache(maxsize=512)
+def _fctp_ins(ins_list):
+    arr = (FctpIns * len(ins_list))()
+    for q, (xo, mu, ao, mv, oo, mw, d, wo, alpha) in zip(arr, ins_list):
+        q.x_off, q.mul_u, q.a_off, q.mul_v, q.out_off, q.mul_w, q.dim, q.w_off, q.alpha = xo, mu, ao, mv, oo, mw, d, wo, alpha
+    return arr
+
+
+_FCTP_WS: "dict[tuple, int]" = {}
+
+
+def _fctp_workspace(ins, n):
+    key = (id(ins), n)  # (the instruction arrays are cached for the life of the process)
+    need = _FCTP_WS.get(key)
+    if need is None:
+        need = _FCTP_WS[key] = int(_lib.lib().tfc_fctp_workspace_floats(ins, len(ins), n))
+    return _gemm_workspace(need) if need > 0 else None
+
+
 def _fctp_fwd(n, x, a, d_a, weight, out, spec, ins_list, on_base):
-    """out[(n,k), w] (+)= alpha sum_{(u,v)} x[n,u,k] a[n,v] W[(u,v), w] for every instruction."""
-    def fwd(xo, mu, ao, mv, oo, mw, d, wo, alpha):
-        return lambda acc: _desc(
-            n * d, mw, mu * mv, _p(x, xo), _p(weight, wo), _p(out, oo),
-            a1_r=_imap(1, d, spec.d_x, 0, 1), a1_k=_imap(1, mv, d, 0, 0),
-            a2=_p(a, ao), a2_r=_imap(1, d, d_a, 0, 0), a2_k=_imap(1, mv, 0, 0, 1),
-            b_k=_lin(mw), b_j=_lin(1), c_r=_imap(1, d, spec.d_out, 0, 1), c_j=_lin(d), alpha=alpha,
-            accumulate=acc or on_base, tag=b"gemm_fctp_fwd",
-        )
-
-    _gemm_waves([(ins[4], fwd(*ins)) for ins in ins_list])
+    """out[(n,k), w] (+)= alpha sum_{(u,v)} x[n,u,k] a[n,v] W[(u,v), w] for every instruction (tfc_fctp_fwd)."""
+    ins = _fctp_ins(tuple(ins_list))
+    ws = _fctp_workspace(ins, n)
+    _lib.check(_lib.lib().tfc_fctp_fwd(ins, len(ins), _ptr(x), _ptr(a), _ptr(weight), n, spec.d_x, d_a, spec.d_out, weight.numel(),
+                                       1 if on_base else 0, _ptr(out), _ptr(ws), ws.numel() if ws is not None else 0, _stream()))
 
 
-def _fctp_dx(n, a, d_a, weight, gt, dx, spec, ins_list):
-    """dx[(n,k), u] = alpha sum_{(v,w)} a[n,v] g[n,w,k] W[u,v,w]   (gt: channel-contiguous g)"""
-    def bdx(xo, mu, ao, mv, oo, mw, d, wo, alpha):
-        return lambda acc: _desc(
-            n * d, mu, mv * mw, _p(a, ao), _p(weight, wo), _p(dx, xo),
-            a1_r=_imap(1, d, d_a, 0, 0), a1_k=_imap(1, mw, 1, 0, 0),
-            a2=_p(gt, oo * n), a2_r=_imap(1, d, mw, 0, n * mw), a2_k=_imap(1, mw, 0, 0, 1),
-            b_k=_lin(1), b_j=_lin(mv * mw), c_r=_imap(1, d, spec.d_x, 0, 1), c_j=_lin(d), alpha=alpha,
-            accumulate=acc, tag=b"gemm_fctp_dx",
-        )
-
-    _gemm_waves([(ins[0], bdx(*ins)) for ins in ins_list])
-
-
-import os as _os
-
-# irrep dimensions whose component sum is folded into the operand of the da product (a_rep)
-_FOLD_DIMS = tuple(int(v) for v in _os.environ.get("TFC_FOLD_DIMS", "3,5").split(",") if v)
-
-
-def _fctp_da(n, xt, weight, gt, spec, ins_list, d_a, a_covered):
-    """da[n, v] = alpha sum_{(k,u,w)} x[n,u,k] g[n,w,k] W[u,v,w].  Every instruction adds to the same
-    block of `da`: each writes its own partial [N, mul_v] in one grouped launch, and the partials
-    are then summed in instruction order (deterministic)."""
-    ni = len(ins_list)
-    part = torch.empty(ni, n, d_a, dtype=torch.float32, device=xt.device)
-    if not a_covered or any(ins[3] != d_a for ins in ins_list):
-        part.zero_()
-    descs = []
-    for i, (xo, mu, ao, mv, oo, mw, d, wo, alpha) in enumerate(ins_list):
-        # (pays while the product has few columns: measured faster at mul_v = 64, slower at 128)
-        fold = d in _FOLD_DIMS and mv <= 64 and mw % 4 == 0 and (oo * n) % 4 == 0 and (n * mw) % 4 == 0 and gt.data_ptr() % 16 == 0
-        if fold:
-            # the sum over the 2l+1 components k is folded into the operand (a_rep): K = mu * mw
-            descs.append(_desc(
-                n, mv, mu * mw, _p(xt, xo * n), _p(weight, wo), _p(part, i * n * d_a + ao),
-                a1_r=_lin(mu), a1_k=_imap(1, mw, 1, 0, 0),
-                a2=_p(gt, oo * n), a2_r=_lin(mw), a2_k=_imap(1, mw, 0, 0, 1),
-                b_k=_imap(1, mw, mv * mw, 0, 1), b_j=_lin(mw), c_r=_lin(d_a), c_j=_lin(1), alpha=alpha,
-                tag=b"gemm_fctp_da", a_rep=d, a1_rs=n * mu, a2_rs=n * mw,
-            ))
-        else:
-            descs.append(_desc(
-                n, mv, d * mu * mw, _p(xt, xo * n), _p(weight, wo), _p(part, i * n * d_a + ao),
-                a1_r=_lin(mu), a1_k=_imap(mu, mw, n * mu, 1, 0),
-                a2=_p(gt, oo * n), a2_r=_lin(mw), a2_k=_imap(mu, mw, n * mw, 0, 1),
-                b_k=_imap(mu, mw, 0, mv * mw, 1), b_j=_lin(mw), c_r=_lin(d_a), c_j=_lin(1), alpha=alpha,
-                tag=b"gemm_fctp_da",
-            ))
-    _gemm_group(descs)
-    return part.sum(dim=0) if ni > 1 else part[0]
-
-
-def _fctp_dw(n, x, a, d_a, gt, dw, spec, ins_list):
-    """dW[(u,v), w] = alpha sum_{(n,k)} x[n,u,k] a[n,v] g[n,w,k]"""
-    _gemm_group([
-        _desc(
-            mu * mv, mw, n * d, _p(x, xo), _p(gt, oo * n), _p(dw, wo),
-            a1_r=_imap(1, mv, d, 0, 0), a1_k=_imap(1, d, spec.d_x, 0, 1),
-            a2=_p(a, ao), a2_r=_imap(1, mv, 0, 0, 1), a2_k=_imap(1, d, d_a, 0, 0),
-            b_k=_imap(1, d, mw, 0, n * mw), b_j=_lin(1), c_r=_lin(mw), c_j=_lin(1), alpha=alpha,
-            tag=b"gemm_fctp_dw",
-        )
-        for xo, mu, ao, mv, oo, mw, d, wo, alpha in ins_list
-    ])
+def _fctp_bwd(n, x, a, d_a, weight, gt, spec, ins_list, dx=None, dw=None, da=None):
+    """tfc_fctp_bwd on a ready-made channel-contiguous gradient copy `gt`: any of
+    dx[(n,k), u] = alpha sum_{(v,w)} a[n,v] g[n,w,k] W[u,v,w],
+    dW[(u,v), w] = alpha sum_{(n,k)} x[n,u,k] a[n,v] g[n,w,k],
+    da[n, v]     = alpha sum_{(k,u,w)} x[n,u,k] g[n,w,k] W[u,v,w]  (per-instruction partials, ordered sum)."""
+    ins = _fctp_ins(tuple(ins_list))
+    L = _lib.lib()
+    xt = part = None
+    if da is not None:
+        xt = torch.empty(max(n * spec.d_x, 1), dtype=torch.float32, device=x.device)
+        part = torch.empty(max(len(ins) * n * d_a, 1), dtype=torch.float32, device=x.device)
+    ws = _fctp_workspace(ins, n)
+    _lib.check(L.tfc_fctp_bwd(ins, len(ins), _ptr(x), _ptr(a), _ptr(weight), None, n, spec.d_x, d_a, spec.d_out, weight.numel(),
+                              _ptr(gt), 1, _ptr(dx), _ptr(dw), _ptr(da), _ptr(xt), _ptr(part), _ptr(ws),
+                              ws.numel() if ws is not None else 0, _stream()))
 
 
 ROUTE_COUNTS = {"fctp_dense": 0, "fctp_low_rank": 0}  # forward calls per self-connection route (read by tests)
@@ -973,53 +936,53 @@ class _FctpFn(torch.autograd.Function):
         # channel-contiguous copies ([dim][N][mul] per block): the contractions below all run over
         # channels, which e3nn's [mul][dim] blocks hold at stride dim
         gt = _ir_transpose(g, spec.out_blocks or [(oo, mw, d) for _, _, _, _, oo, mw, d, _, _ in spec.instructions])
+        low = ctx.low is not None
+        project_da = low and ctx.factors.promised and ctx.needs_input_grad[1]
         if ctx.needs_input_grad[0]:
             dx = (torch.empty if spec.x_covered else torch.zeros)(n, spec.d_x, dtype=torch.float32, device=x.device)
-            if ctx.low is None:
-                _fctp_dx(n, a, spec.d_a, weight, gt, dx, spec, spec.instructions)
-            else:
-                _fctp_dx(n, Cm, Cm.shape[1], wp, gt, dx, spec, ctx.low)
-        project_da = ctx.low is not None and ctx.factors.promised and ctx.needs_input_grad[1]
         if ctx.needs_input_grad[1] and not project_da:
-            xt = _ir_transpose(x, [(xo, mu, d) for xo, mu, _, _, _, _, d, _, _ in spec.instructions])
-            da = _fctp_da(n, xt, weight, gt, spec, spec.instructions, spec.d_a, spec.a_covered)
-        if ctx.needs_input_grad[2] or project_da:
-            if ctx.low is None:
+            da = (torch.empty if spec.a_covered else torch.zeros)(n, spec.d_a, dtype=torch.float32, device=x.device)
+        if not low:
+            if ctx.needs_input_grad[2]:
                 dw = torch.empty_like(weight)
-                _fctp_dw(n, x, a, spec.d_a, gt, dw, spec, spec.instructions)
-            else:
-                r = Cm.shape[1]
-                dwp = torch.empty_like(wp)
-                _fctp_dw(n, x, Cm, r, gt, dwp, spec, ctx.low)
-                if ctx.needs_input_grad[2]:
-                    # dW[u, v, w] = sum_s R[s, v] dW'[u, s, w]
-                    dw = torch.empty_like(weight)
-                    _gemm_group([
-                        _desc(
-                            mv, mu * mw, r, _p(R, ao), _p(dwp, lo[7]), _p(dw, wo),
-                            a1_r=_lin(1), a1_k=_lin(spec.d_a), b_k=_lin(mw), b_j=_imap(1, mw, r * mw, 0, 1),
-                            c_r=_lin(mw), c_j=_imap(1, mw, mv * mw, 0, 1), tag=b"gemm_fctp_lowrank_w",
-                        )
-                        for (xo, mu, ao, mv, oo, mw, d, wo, alpha), lo in zip(spec.instructions, ctx.low)
-                    ])
-                if project_da:
-                    # dR[s, v] = sum_{u,w} dW'[u, s, w] W[u, v, w]: the gradient of the distinct rows; every row
-                    # of a class then receives its class mean (sums back to dR through any lookup a = R[class])
-                    ni = len(spec.instructions)
-                    part = torch.empty(ni, r, spec.d_a, dtype=torch.float32, device=x.device)
-                    if not spec.a_covered or any(ins[3] != spec.d_a for ins in spec.instructions):
-                        part.zero_()
-                    _gemm_group([
-                        _desc(
-                            r, mv, mu * mw, _p(dwp, lo[7]), _p(weight, wo), _p(part, i * r * spec.d_a + ao),
-                            a1_r=_lin(mw), a1_k=_imap(1, mw, r * mw, 0, 1),
-                            b_k=_imap(1, mw, mv * mw, 0, 1), b_j=_lin(mw), c_r=_lin(spec.d_a), c_j=_lin(1),
-                            tag=b"gemm_fctp_da_rows",
-                        )
-                        for i, ((xo, mu, ao, mv, oo, mw, d, wo, alpha), lo) in enumerate(zip(spec.instructions, ctx.low))
-                    ])
-                    d_rows = (part.sum(dim=0) if ni > 1 else part[0]) * ctx.factors.inv_count[:, None]
-                    da = d_rows[ctx.factors.inv]
+            if dx is not None or dw is not None or da is not None:
+                _fctp_bwd(n, x, a, spec.d_a, weight, gt, spec, spec.instructions, dx=dx, dw=dw, da=da)
+        else:
+            r = Cm.shape[1]
+            dwp = torch.empty_like(wp) if (ctx.needs_input_grad[2] or project_da) else None
+            if dx is not None or dwp is not None:
+                _fctp_bwd(n, x, Cm, r, wp, gt, spec, ctx.low, dx=dx, dw=dwp)
+            if da is not None:  # classes found by inspection: the per-node attribute gradient, dense
+                _fctp_bwd(n, x, a, spec.d_a, weight, gt, spec, spec.instructions, da=da)
+            if ctx.needs_input_grad[2]:
+                # dW[u, v, w] = sum_s R[s, v] dW'[u, s, w]
+                dw = torch.empty_like(weight)
+                _gemm_group([
+                    _desc(
+                        mv, mu * mw, r, _p(R, ao), _p(dwp, lo[7]), _p(dw, wo),
+                        a1_r=_lin(1), a1_k=_lin(spec.d_a), b_k=_lin(mw), b_j=_imap(1, mw, r * mw, 0, 1),
+                        c_r=_lin(mw), c_j=_imap(1, mw, mv * mw, 0, 1), tag=b"gemm_fctp_lowrank_w",
+                    )
+                    for (xo, mu, ao, mv, oo, mw, d, wo, alpha), lo in zip(spec.instructions, ctx.low)
+                ])
+            if project_da:
+                # dR[s, v] = sum_{u,w} dW'[u, s, w] W[u, v, w]: the gradient of the distinct rows; every row
+                # of a class then receives its class mean (sums back to dR through any lookup a = R[class])
+                ni = len(spec.instructions)
+                part = torch.empty(ni, r, spec.d_a, dtype=torch.float32, device=x.device)
+                if not spec.a_covered or any(ins[3] != spec.d_a for ins in spec.instructions):
+                    part.zero_()
+                _gemm_group([
+                    _desc(
+                        r, mv, mu * mw, _p(dwp, lo[7]), _p(weight, wo), _p(part, i * r * spec.d_a + ao),
+                        a1_r=_lin(mw), a1_k=_imap(1, mw, r * mw, 0, 1),
+                        b_k=_imap(1, mw, mv * mw, 0, 1), b_j=_lin(mw), c_r=_lin(spec.d_a), c_j=_lin(1),
+                        tag=b"gemm_fctp_da_rows",
+                    )
+                    for i, ((xo, mu, ao, mv, oo, mw, d, wo, alpha), lo) in enumerate(zip(spec.instructions, ctx.low))
+                ])
+                d_rows = (part.sum(dim=0) if ni > 1 else part[0]) * ctx.factors.inv_count[:, None]
+                da = d_rows[ctx.factors.inv]
         return dx, da, dw, None, (g if ctx.has_base else None), None
 
 

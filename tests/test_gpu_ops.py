@@ -754,3 +754,48 @@ def test_radial_mlp_bwd_c_entry_point(device, dims, rows):
     _lib.check(L.tfc_radial_mlp_bwd(P(xd), rows, nl, c_dims, vp(wd), cst, vp(hid), P(god), vp(dhid), None, vp(dws2), None, 0, ops._stream()))
     for a, b in zip(dws2[1:], ref[2:]):
         assert rel(a, b) < TOL
+
+
+def test_fctp_c_entry_points(device):
+    """tfc_fctp_fwd / tfc_fctp_bwd called directly, against the oracle's FullyConnectedTensorProduct:
+    forward on top of a base, then dx, dW and the per-node da with gout handed over untransposed."""
+    from matten_amd import _lib, ops
+    from matten_amd.nn.e3 import FullyConnectedTensorProduct
+    from oracle import e3ref
+
+    in1, in2, out = "12x0e+8x1o+4x2e", "16x0e", "10x0o+20x0e+8x1o+4x2e"
+    torch.manual_seed(80)
+    o = e3ref.FullyConnectedTensorProduct(in1, in2, out).double()
+    h = FullyConnectedTensorProduct(in1, in2, out)  # only its instruction table is used
+    spec = h.spec
+    n = 90
+    x = torch.randn(n, spec.d_x, dtype=torch.float64, requires_grad=True)
+    a = torch.randn(n, spec.d_a, dtype=torch.float64, requires_grad=True)
+    base = torch.randn(n, spec.d_out, dtype=torch.float64)
+    y = base + o(x, a)
+    go = torch.randn_like(y)
+    gx, ga, gw = torch.autograd.grad(y, [x, a, o.weight], go)
+
+    L = _lib.lib()
+    P, st = ops._ptr, ops._stream()
+    ins = ops._fctp_ins(tuple(spec.instructions))
+    f = lambda t: t.detach().float().to(device).contiguous()  # noqa: E731
+    xd, ad, wd, god, outd = f(x), f(a), f(o.weight), f(go), f(base)
+    wn = wd.numel()
+    _lib.check(L.tfc_fctp_fwd(ins, len(ins), P(xd), P(ad), P(wd), n, spec.d_x, spec.d_a, spec.d_out, wn, 1, P(outd), None, 0, st))
+    assert rel(outd, y) < TOL
+    gt = torch.empty(n * spec.d_out, device=device)
+    dx = torch.zeros(n, spec.d_x, device=device)
+    da = torch.zeros(n, spec.d_a, device=device)
+    dw = torch.empty(wn, device=device)
+    xt = torch.empty(n * spec.d_x, device=device)
+    part = torch.empty(len(ins) * n * spec.d_a, device=device)
+    need = int(L.tfc_fctp_workspace_floats(ins, len(ins), n))
+    ws = torch.empty(max(need, 1), device=device)
+    _lib.check(L.tfc_fctp_bwd(ins, len(ins), P(xd), P(ad), P(wd), P(god), n, spec.d_x, spec.d_a, spec.d_out, wn, P(gt), 0,
+                              P(dx), P(dw), P(da), P(xt), P(part), P(ws), need, st))
+    assert rel(dx, gx) < TOL and rel(da, ga) < TOL and rel(dw, gw) < TOL
+    # da without its scratch is refused; a bad instruction too
+    assert L.tfc_fctp_bwd(ins, len(ins), P(xd), P(ad), P(wd), P(god), n, spec.d_x, spec.d_a, spec.d_out, wn, P(gt), 0,
+                          None, None, P(da), None, None, None, 0, st) < 0
+    assert L.tfc_fctp_fwd(ins, len(ins), P(xd), P(ad), P(wd), n, spec.d_x, spec.d_a, spec.d_out, wn - 1, 0, P(outd), None, 0, st) < 0
