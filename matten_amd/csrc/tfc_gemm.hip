@@ -662,9 +662,9 @@ long max_splits(long m, long n, long k) {
 // one launch: problems with equal operand walking order, at most MAXP of them
 int launch_group(Group& g, const Flags& f, float* workspace, long workspace_floats, const char* tag,
                  hipStream_t stream) {
-    // tile: the largest one that still fills the chip (counting the K ranges a problem can be cut
-    // into) and does not pad the problems much (a
-    // 128-wide tile on a 64-column problem would spend half its MFMAs on padding)
+    // tile: the largest one that still fills the chip several times over (counting the K ranges a
+    // problem can be cut into) and does not pad the problems much (a 128-wide tile on a 64-column
+    // problem would spend half its MFMAs on padding)
     const int cand[3][2] = {{128, 128}, {128, 64}, {64, 64}};
     long blocks[3], padded[3];
     for (int c = 0; c < 3; ++c) {
@@ -676,8 +676,12 @@ int launch_group(Group& g, const Flags& f, float* workspace, long workspace_floa
         }
     }
     int pick = 2;
+    // a larger tile must still leave ~8 workgroups per CU: below that the launch is latency-bound and
+    // twice as many 64 x 64 workgroups finish sooner (measured: config 3 step 4.19 -> 3.97 ms, config 5
+    // 5.62 -> 5.42, config 4 unchanged; no threshold at all loses 1 % at config 4)
+    static const long min_blocks = getenv("TFC_GEMM_MIN_BLOCKS") ? atol(getenv("TFC_GEMM_MIN_BLOCKS")) : 2048;
     for (int c = 1; c >= 0 && f.rep == 1; --c)  // the repeated-factor staging exists for the 64 x 64 tile only
-        if (blocks[c] >= 256 && padded[c] * 100 <= padded[2] * 112) pick = c;
+        if (blocks[c] >= min_blocks && padded[c] * 100 <= padded[2] * 112) pick = c;
     const int bm = cand[pick][0], bn = cand[pick][1];
     // K ranges.  All blocks of a launch should carry a similar number of K tiles (the problems of
     // a group differ in K by up to 2 l + 1 and in the number of tiles by more), and a launch with
