@@ -399,17 +399,40 @@ __global__ __launch_bounds__(256, (TM * TN == 4 ? 4 : 1)) void tfc_gemm_kernel(c
 }
 
 // second stage of split-K: ordered sum of the partial slabs, then the usual epilogue
+// A workgroup owns 64 consecutive elements; its four waves each sum a quarter of the slabs (a
+// contiguous z range, ascending), and wave 0 adds the four quarter sums in order: a fixed
+// association, so the result does not depend on the launch, and the serial chain of a long split
+// (up to 64 slabs) is a quarter as long and spread over four times as many CUs for small outputs.
 __global__ __launch_bounds__(256) void tfc_gemm_reduce_kernel(const Group g) {
     const Problem& P = g.p[blockIdx.y];
     if (P.splits <= 1) return;
+    __shared__ float part[4][64];
     const long total = (long)P.m * P.n;
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
-         i += (long)gridDim.x * blockDim.x) {
-        const int row = (int)(i / P.n), col = (int)(i - (long)row * P.n);
+    const int lane = threadIdx.x & 63, q = threadIdx.x >> 6;
+    const int per = (P.splits + 3) >> 2;
+    const int z0 = q * per, z1 = min(P.splits, z0 + per);
+    for (long base = (long)blockIdx.x * 64; base < total; base += (long)gridDim.x * 64) {
+        const long i = base + lane;
         float s = 0.f;
-        for (int z = 0; z < P.splits; ++z) s += P.slab[(long)z * total + i];
-        const long o = map_eval(P.c_r, row) + map_eval(P.c_j, col);
-        P.c[o] = epilogue_apply(P, s, o);
+        if (i < total) {
+            const float* src = P.slab + i;
+            int z = z0;
+            for (; z + 4 <= z1; z += 4) {
+                const float v0 = src[(long)z * total], v1 = src[(long)(z + 1) * total];
+                const float v2 = src[(long)(z + 2) * total], v3 = src[(long)(z + 3) * total];
+                s = ((s + v0) + v1) + v2 + v3;
+            }
+            for (; z < z1; ++z) s += src[(long)z * total];
+        }
+        part[q][lane] = s;
+        __syncthreads();
+        if (q == 0 && i < total) {
+            s = ((part[0][lane] + part[1][lane]) + part[2][lane]) + part[3][lane];
+            const int row = (int)(i / P.n), col = (int)(i - (long)row * P.n);
+            const long o = map_eval(P.c_r, row) + map_eval(P.c_j, col);
+            P.c[o] = epilogue_apply(P, s, o);
+        }
+        __syncthreads();
     }
 }
 
@@ -643,7 +666,7 @@ int launch_tile(Group& g, const Flags& f, const char* tag, hipStream_t stream) {
         long big = 1;
         for (int i = 0; i < g.n; ++i)
             if (g.p[i].splits > 1) big = std::max(big, (long)g.p[i].m * g.p[i].n);
-        const dim3 rgrid((unsigned)std::min<long>(cdiv(big, 256), 1024), (unsigned)g.n);
+        const dim3 rgrid((unsigned)std::min<long>(cdiv(big, 64), 8192), (unsigned)g.n);
         tfc_gemm_reduce_kernel<<<rgrid, block, 0, stream>>>(g);
         TFC_LAUNCH_CHECK("tfc_gemm_reduce_kernel");
     }

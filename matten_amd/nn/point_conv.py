@@ -67,11 +67,23 @@ class PointConvMessage(ModuleIrreps, torch.nn.Module):
         self.aggregation_scale = 1.0
 
     def forward(self, data: DataKey.Type) -> DataKey.Type:
+        emb = data[DataKey.EDGE_EMBEDDING]
+        w = None
+        if self.fuse_aggregation and ops.MLP_SIDE_STREAM and self.tp.weight_nn is not None and emb.is_cuda:
+            # the radial network beside linear_1 (and, in backward, beside the next convolution backward)
+            main, side = torch.cuda.current_stream(emb.device), ops.side_stream(emb.device)
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                w = self.tp.weight_nn(emb)
+            emb.record_stream(side)
         x = self.linear_1(data[DataKey.NODE_FEATURES])
+        if w is not None:
+            main.wait_stream(side)
+            w.record_stream(main)
         ordering = ops.edge_ordering(data[DataKey.EDGE_INDEX], x.shape[0])
         if self.fuse_aggregation:
             data[_NODE_MESSAGE] = self.tp(
-                x, data[DataKey.EDGE_ATTRS], data[DataKey.EDGE_EMBEDDING], ordering=ordering, scale=self.aggregation_scale
+                x, data[DataKey.EDGE_ATTRS], emb, ordering=ordering, scale=self.aggregation_scale, weight=w
             )
             data.pop(DataKey.EDGE_MESSAGE, None)
         else:

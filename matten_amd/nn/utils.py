@@ -142,8 +142,13 @@ class UVUTensorProduct(torch.nn.Module):
             layer_sizes = [mlp_input_size] + mlp_num_hidden_layers * [mlp_hidden_size] + [self.tp.weight_numel]
             self.weight_nn = FullyConnectedNet(layer_sizes, act=act)
 
-    def forward(self, data1, data2, data_weight=None, *, ordering: Optional[ops.EdgeOrdering] = None, scale: float = 1.0):
-        if self.weight_nn is not None:
+    def forward(self, data1, data2, data_weight=None, *, ordering: Optional[ops.EdgeOrdering] = None, scale: float = 1.0,
+                weight: Optional[torch.Tensor] = None):
+        """`weight`: per-edge weights already computed by `self.weight_nn` (the caller ran it elsewhere,
+        e.g. on a side stream); otherwise they are computed here from `data_weight`, as in the reference."""
+        if weight is not None:
+            pass
+        elif self.weight_nn is not None:
             assert data_weight is not None, "data for weight not provided"
             weight = self.weight_nn(data_weight)
         else:

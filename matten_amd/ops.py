@@ -12,6 +12,7 @@ import ctypes as C
 import functools
 import math
 import weakref
+from os import environ as _os_environ
 from dataclasses import dataclass
 from typing import List, NamedTuple, Optional, Sequence, Tuple
 
@@ -474,17 +475,35 @@ def _ws_floats(m: int, n: int, k: int) -> int:
     return int(_lib.lib().tfc_gemm_workspace_floats(m, n, k))
 
 
-_GEMM_WS: "dict[int, torch.Tensor]" = {}
+_GEMM_WS: "dict[tuple, torch.Tensor]" = {}
 
 
 def _gemm_workspace(n_floats: int) -> torch.Tensor:
-    """Per-device scratch for split-K, reused by every call (calls are stream ordered)."""
+    """Scratch for split-K, one per (device, stream), reused by every call on that stream (calls on
+    one stream are ordered; two streams must not share it)."""
     dev = torch.cuda.current_device()
-    ws = _GEMM_WS.get(dev)
+    key = (dev, torch._C._cuda_getCurrentRawStream(dev))
+    ws = _GEMM_WS.get(key)
     if ws is None or ws.numel() < n_floats:
         ws = torch.empty(max(n_floats, 1 << 22), dtype=torch.float32, device=torch.device("cuda", dev))
-        _GEMM_WS[dev] = ws
+        _GEMM_WS[key] = ws
     return ws
+
+
+# The radial network of a layer depends on the edge embedding only, not on the node features: its
+# forward can run beside linear_1, and - because autograd runs a node's backward on the stream of
+# its forward - its backward (three MFMA-bound products per layer) runs beside the HBM-bound
+# convolution backward of the layer below.  TFC_MLP_SIDE_STREAM=0 keeps everything on one stream.
+MLP_SIDE_STREAM = _os_environ.get("TFC_MLP_SIDE_STREAM", "1") != "0"
+_SIDE_STREAMS: "dict[int, torch.cuda.Stream]" = {}
+
+
+def side_stream(device: torch.device) -> "torch.cuda.Stream":
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    st = _SIDE_STREAMS.get(idx)
+    if st is None:
+        st = _SIDE_STREAMS[idx] = torch.cuda.Stream(device=idx)
+    return st
 
 
 def _desc(m, n, k, a1, b, c, a1_r, a1_k, b_k, b_j, c_r, c_j, alpha=1.0, accumulate=False, a2=None, a2_r=None, a2_k=None,
