@@ -86,6 +86,47 @@ int tfc_gather_rows(const float* src, const int64_t* index, int64_t n_rows, int6
                     float* out, tfc_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Periodic neighbour list of a batch of structures.  Replaces neighbor_list_and_relative_vec
+ * (eigenn/data/data.py:400-528): ase.neighborlist.primitive_neighbor_list("ijS", pbc, cell, pos,
+ * cutoff=r_max, self_interaction=True) (:480-489) followed by the removal of the (i == j, S == 0)
+ * edges (:491-502).  The result is the set of all (i, j, S) with
+ * |pos[j] - pos[i] + S @ cell| < r_max (strict; fp64, no fused multiply-add), in the canonical order
+ * (i, j, Sx, Sy, Sz) - ASE's own order inside equal i is not reproducible, so parity is equality of
+ * sets; edge_index[0] is non-decreasing as ASE delivers it.
+ *
+ *   pos        : [N,3] double   positions of all structures, concatenated
+ *   node_graph : [N] int32      structure of each node
+ *   graph_ptr  : [G+1] int32    nodes of structure g are graph_ptr[g] .. graph_ptr[g+1]
+ *   shift_ptr  : [G+1] int32    rows of `shifts` / `shift_vec` that belong to structure g
+ *   shifts     : [S,3] int32    periodic images to test, ascending lexicographic inside a structure
+ *                               (the caller enumerates them: ceil(r_max / face distance) + spread per
+ *                               periodic axis, matten_amd/data/neighbor.py), (0,0,0) included
+ *   shift_vec  : [S,3] double   shifts @ cell of that structure
+ *
+ * tfc_nl_count -> row_ptr [N+1] int32: edges of sender i will occupy row_ptr[i] .. row_ptr[i+1];
+ * the caller reads E = row_ptr[N], allocates, and calls tfc_nl_fill with the same arguments ->
+ * edge_index [2,E] int64 (row 0 sender i, row 1 receiver j, global node ids) and edge_shift [E,3]
+ * float32 (the dtype the reference stores, data.py:509-513).  No sort and no atomics: one wave walks
+ * a node's candidates in canonical order and writes at ballot-prefix positions.
+ *
+ * tfc_nl_ordering: both groupings the convolution needs (tfc_csr_build's outputs for key = row 0 and
+ * key = row 1), derived from the symmetry (i, j, S) <-> (j, i, -S) of such a list instead of a sort;
+ * both share `row_ptr`.  status [1] int32: 0, 1 if the list is not symmetric (a pair within rounding
+ * of the cutoff: use tfc_csr_build), 2 if an index is outside [0, N); on non-zero status the dst
+ * arrays are incomplete and must not be used.
+ */
+int tfc_nl_count(const double* pos, const int32_t* node_graph, const int32_t* graph_ptr,
+                 const int32_t* shift_ptr, const int32_t* shifts, const double* shift_vec, int64_t n_nodes,
+                 int64_t n_graphs, double r_max, int32_t* row_ptr, tfc_stream_t stream);
+int tfc_nl_fill(const double* pos, const int32_t* node_graph, const int32_t* graph_ptr,
+                const int32_t* shift_ptr, const int32_t* shifts, const double* shift_vec, int64_t n_nodes,
+                int64_t n_graphs, double r_max, const int32_t* row_ptr, int64_t n_edges, int64_t* edge_index,
+                float* edge_shift, tfc_stream_t stream);
+int tfc_nl_ordering(const int64_t* edge_index, const int32_t* row_ptr, int64_t n_edges, int64_t n_nodes,
+                    int32_t* src_eid, int32_t* src_nbr, int32_t* dst_eid, int32_t* dst_nbr, int32_t* status,
+                    tfc_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
  * 'uvu' tensor product with per-edge weights, fused with the gather of sender features and
  * the sum over each receiver's edges.
  *

@@ -18,18 +18,10 @@ from typing import Sequence, Tuple, Union
 import numpy as np
 
 
-def neighbor_list(
-    pos: np.ndarray, cell: np.ndarray, pbc: Union[bool, Sequence[bool]], r_max: float, chunk: int = 2048
-) -> Tuple[np.ndarray, np.ndarray, np.ndarray]:
-    """Returns (edge_index [2,E] int64, shifts [E,3] int64, num_neigh [N] int64)."""
-    pos = np.asarray(pos, dtype=np.float64).reshape(-1, 3)
-    cell = np.asarray(cell, dtype=np.float64).reshape(3, 3)
-    if isinstance(pbc, (bool, np.bool_)):
-        pbc = (bool(pbc),) * 3
-    pbc = tuple(bool(b) for b in pbc)
+def image_table(pos: np.ndarray, cell: np.ndarray, pbc: Sequence[bool], r_max: float) -> np.ndarray:
+    """The periodic images [S,3] (int64, ascending lexicographic, (0,0,0) included) that can hold a
+    neighbour within r_max of an atom of this structure."""
     n = len(pos)
-    r_max = float(r_max)
-
     # images needed along axis a: the cutoff sphere spans ceil(r_max / h_a) cells, h_a = distance
     # between the cell faces normal to reciprocal vector a; +1 because atoms need not be wrapped
     reps = [0, 0, 0]
@@ -43,7 +35,22 @@ def neighbor_list(
             if pbc[a]:
                 h = vol / np.linalg.norm(np.cross(cell[(a + 1) % 3], cell[(a + 2) % 3]))
                 reps[a] = int(math.ceil(r_max / h)) + int(spread[a])
-    shifts = np.array(list(itertools.product(*[range(-r, r + 1) for r in reps])), dtype=np.int64)
+    return np.array(list(itertools.product(*[range(-r, r + 1) for r in reps])), dtype=np.int64)
+
+
+def neighbor_list(
+    pos: np.ndarray, cell: np.ndarray, pbc: Union[bool, Sequence[bool]], r_max: float, chunk: int = 2048
+) -> Tuple[np.ndarray, np.ndarray, np.ndarray]:
+    """Returns (edge_index [2,E] int64, shifts [E,3] int64, num_neigh [N] int64)."""
+    pos = np.asarray(pos, dtype=np.float64).reshape(-1, 3)
+    cell = np.asarray(cell, dtype=np.float64).reshape(3, 3)
+    if isinstance(pbc, (bool, np.bool_)):
+        pbc = (bool(pbc),) * 3
+    pbc = tuple(bool(b) for b in pbc)
+    n = len(pos)
+    r_max = float(r_max)
+
+    shifts = image_table(pos, cell, pbc, r_max)
     shift_vec = shifts.astype(np.float64) @ cell  # [S,3]
 
     out_i, out_j, out_s = [], [], []

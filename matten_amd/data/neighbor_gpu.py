@@ -1,0 +1,81 @@
+"""Neighbour lists of a whole batch of structures on the GPU (tfc_nl_count / tfc_nl_fill), with the
+semantics of the reference's `neighbor_list_and_relative_vec` (eigenn/data/data.py:400-528) and the
+canonical edge order of `matten_amd.data.neighbor.neighbor_list`: the two agree array for array.
+
+The host enumerates the periodic images of each structure (a few dozen rows; `image_table`) and the
+image vectors in fp64; the distance tests, the compaction and - because such a list is symmetric -
+both edge groupings the convolution reduces over (tfc_nl_ordering, no sort) run on the device.
+One host synchronisation (the edge count).  No CPU fallback: a CPU device is refused.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, Sequence
+
+import numpy as np
+import torch
+
+from .. import _lib, ops
+from .neighbor import image_table
+
+
+def neighbor_list_batch(structures: Sequence[Dict[str, np.ndarray]], r_max: float, device, with_ordering: bool = True):
+    """structures: dicts with `pos` [n,3], `cell` [3,3], optional `pbc` (default fully periodic).
+    Returns a dict: `edge_index` [2,E] int64 (global node ids, offset as PyG's collate does),
+    `edge_cell_shift` [E,3] float32, `num_neigh` [N] int64, `row_ptr` [N+1] int32, `ptr` [G+1] int64 and,
+    with `with_ordering`, `ordering` (ops.EdgeOrdering, also registered for `edge_index`)."""
+    device = torch.device(device)
+    if device.type != "cuda":
+        raise RuntimeError("matten_amd: the GPU neighbour list needs a ROCm device (use data.neighbor.neighbor_list on the host)")
+    r_max = float(r_max)
+    pos_l, node_graph, graph_ptr, shift_ptr, shifts_l, svec_l = [], [], [0], [0], [], []
+    for g, st in enumerate(structures):
+        pos = np.asarray(st["pos"], dtype=np.float64).reshape(-1, 3)
+        cell = np.asarray(st["cell"], dtype=np.float64).reshape(3, 3)
+        pbc = st.get("pbc", True)
+        pbc = (bool(pbc),) * 3 if isinstance(pbc, (bool, np.bool_)) else tuple(bool(b) for b in pbc)
+        sh = image_table(pos, cell, pbc, r_max)
+        pos_l.append(pos)
+        node_graph.append(np.full(len(pos), g, dtype=np.int32))
+        graph_ptr.append(graph_ptr[-1] + len(pos))
+        shifts_l.append(sh.astype(np.int32))
+        svec_l.append(sh.astype(np.float64) @ cell)
+        shift_ptr.append(shift_ptr[-1] + len(sh))
+    G, N = len(structures), graph_ptr[-1]
+    if N == 0:
+        raise ValueError("After eliminating self edges, no edges remain in this system.")
+
+    def dev(a, dtype):
+        return torch.as_tensor(np.ascontiguousarray(a), dtype=dtype).to(device)
+
+    pos_d = dev(np.concatenate(pos_l), torch.float64)
+    ng_d = dev(np.concatenate(node_graph), torch.int32)
+    gp_d = dev(np.array(graph_ptr), torch.int32)
+    sp_d = dev(np.array(shift_ptr), torch.int32)
+    sh_d = dev(np.concatenate(shifts_l), torch.int32)
+    sv_d = dev(np.concatenate(svec_l), torch.float64)
+    row_ptr = torch.empty(N + 1, dtype=torch.int32, device=device)
+    L = _lib.lib()
+    with torch.cuda.device(device):
+        common = (ops._ptr(pos_d), ops._ptr(ng_d), ops._ptr(gp_d), ops._ptr(sp_d), ops._ptr(sh_d), ops._ptr(sv_d), N, G,
+                  C.c_double(r_max))
+        _lib.check(L.tfc_nl_count(*common, ops._ptr(row_ptr), ops._stream()))
+        rp_host = row_ptr.cpu().numpy()  # the one synchronisation
+        per_graph = rp_host[np.array(graph_ptr[1:])] - rp_host[np.array(graph_ptr[:-1])]
+        if np.any(per_graph == 0):
+            # the reference raises per structure (eigenn/data/data.py:497-502)
+            raise ValueError("After eliminating self edges, no edges remain in this system.")
+        E = int(rp_host[-1])
+        edge_index = torch.empty((2, E), dtype=torch.int64, device=device)
+        edge_shift = torch.empty((E, 3), dtype=torch.float32, device=device)
+        _lib.check(L.tfc_nl_fill(*common, ops._ptr(row_ptr), E, ops._ptr(edge_index), ops._ptr(edge_shift), ops._stream()))
+        out = {
+            "edge_index": edge_index,
+            "edge_cell_shift": edge_shift,
+            "num_neigh": torch.as_tensor(np.diff(rp_host).astype(np.int64)).to(device),
+            "row_ptr": row_ptr,
+            "ptr": torch.as_tensor(np.array(graph_ptr, dtype=np.int64)).to(device),
+        }
+        if with_ordering:
+            out["ordering"] = ops.EdgeOrdering.from_neighbor_list(edge_index, N, row_ptr)
+    return out

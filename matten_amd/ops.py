@@ -100,6 +100,35 @@ class EdgeOrdering:
         self._edge_rows = None
         self._m_cache = {}
 
+    @classmethod
+    def from_neighbor_list(cls, edge_index: torch.Tensor, n_nodes: int, row_ptr: torch.Tensor) -> "EdgeOrdering":
+        """Ordering of a symmetric, canonically ordered neighbour list (tfc_nl_fill's output) without
+        the sort: tfc_nl_ordering.  Falls back to the general builder if the list turns out not to be
+        symmetric (one host synchronisation to read that flag).  Registered for `edge_index`, so the
+        layers that later see this tensor reuse it."""
+        self = cls.__new__(cls)
+        ei = edge_index.contiguous()
+        if ei.dtype != torch.int64 or not ei.is_cuda or ei.dim() != 2 or ei.shape[0] != 2:
+            raise ValueError("from_neighbor_list: edge_index must be a [2, E] int64 tensor on a ROCm device")
+        E, N, dev = int(ei.shape[1]), int(n_nodes), ei.device
+        if row_ptr.dtype != torch.int32 or row_ptr.numel() != N + 1 or row_ptr.device != dev:
+            raise ValueError("from_neighbor_list: row_ptr must be [N + 1] int32 on the device of edge_index")
+        self.edge_index, self.n_nodes, self.n_edges = ei, N, E
+        self.status = torch.zeros(2, dtype=torch.int32, device=dev)
+        arrs = [torch.empty(max(E, 1), dtype=torch.int32, device=dev) for _ in range(4)]
+        flag = torch.zeros(1, dtype=torch.int32, device=dev)
+        with torch.cuda.device(dev):
+            _lib.check(_lib.lib().tfc_nl_ordering(_ptr(ei), _ptr(row_ptr), E, N, *[_ptr(a) for a in arrs], _ptr(flag), _stream()))
+        if int(flag.item()) != 0:
+            return edge_ordering(edge_index, n_nodes)
+        rp = row_ptr.contiguous()
+        self.by_src = (rp, arrs[0], arrs[1])
+        self.by_dst = (rp, arrs[2], arrs[3])
+        self._edge_rows = None
+        self._m_cache = {}
+        _ORDER_CACHE[id(edge_index)] = (weakref.ref(edge_index), edge_index._version, N, self)
+        return self
+
     def m_matrices(self, plan: "ConvPlan", y: torch.Tensor, rows) -> torch.Tensor:
         """The per-edge matrices M_e (CG tensor contracted with the edge attributes) in the order of
         `rows`, built once and shared by every layer whose plan lays M out the same way (and that

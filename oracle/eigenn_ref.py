@@ -483,8 +483,11 @@ def neighbor_list_bruteforce(pos, cell, pbc, r_max):
     cell = np.asarray(cell, dtype=np.float64).reshape(3, 3)
     pbc = [bool(b) for b in (pbc if hasattr(pbc, "__len__") else (pbc,) * 3)]
     n = len(pos)
-    # number of images needed along each axis: r_max / (distance between cell faces)
+    # number of images needed along each axis: r_max / (distance between cell faces), plus the
+    # number of cells the (not necessarily wrapped) atoms themselves are spread over
     vol = abs(np.linalg.det(cell))
+    frac = pos @ np.linalg.inv(cell) if any(pbc) else np.zeros_like(pos)
+    spread = np.ceil(frac.max(0) - frac.min(0)).astype(int) if n else np.zeros(3, int)
     reps = []
     for a in range(3):
         if not pbc[a]:
@@ -492,7 +495,7 @@ def neighbor_list_bruteforce(pos, cell, pbc, r_max):
             continue
         b, c = cell[(a + 1) % 3], cell[(a + 2) % 3]
         h = vol / np.linalg.norm(np.cross(b, c))
-        reps.append(int(math.ceil(r_max / h)) + 1)
+        reps.append(int(math.ceil(r_max / h)) + max(1, int(spread[a])))
     out = []
     frac_span = [range(-r, r + 1) for r in reps]
     import itertools
