@@ -102,6 +102,10 @@ int tfc_gather_rows(const float* src, const int64_t* index, int64_t n_rows, int6
  *                               (the caller enumerates them: ceil(r_max / face distance) + spread per
  *                               periodic axis, matten_amd/data/neighbor.py), (0,0,0) included
  *   shift_vec  : [S,3] double   shifts @ cell of that structure
+ *   graph_box  : [G,6] double   (min x,y,z, max x,y,z) of each structure's positions, or null.  With it,
+ *                               every node first drops the images whose moved box stays farther than
+ *                               r_max away (a conservative test: the result is the same set), which
+ *                               leaves 1-8 of the 27-125 images of the bench cells.
  *
  * tfc_nl_count -> row_ptr [N+1] int32: edges of sender i will occupy row_ptr[i] .. row_ptr[i+1];
  * the caller reads E = row_ptr[N], allocates, and calls tfc_nl_fill with the same arguments ->
@@ -116,12 +120,13 @@ int tfc_gather_rows(const float* src, const int64_t* index, int64_t n_rows, int6
  * arrays are incomplete and must not be used.
  */
 int tfc_nl_count(const double* pos, const int32_t* node_graph, const int32_t* graph_ptr,
-                 const int32_t* shift_ptr, const int32_t* shifts, const double* shift_vec, int64_t n_nodes,
-                 int64_t n_graphs, double r_max, int32_t* row_ptr, tfc_stream_t stream);
+                 const int32_t* shift_ptr, const int32_t* shifts, const double* shift_vec,
+                 const double* graph_box, int64_t n_nodes, int64_t n_graphs, double r_max, int32_t* row_ptr,
+                 tfc_stream_t stream);
 int tfc_nl_fill(const double* pos, const int32_t* node_graph, const int32_t* graph_ptr,
-                const int32_t* shift_ptr, const int32_t* shifts, const double* shift_vec, int64_t n_nodes,
-                int64_t n_graphs, double r_max, const int32_t* row_ptr, int64_t n_edges, int64_t* edge_index,
-                float* edge_shift, tfc_stream_t stream);
+                const int32_t* shift_ptr, const int32_t* shifts, const double* shift_vec,
+                const double* graph_box, int64_t n_nodes, int64_t n_graphs, double r_max, const int32_t* row_ptr,
+                int64_t n_edges, int64_t* edge_index, float* edge_shift, tfc_stream_t stream);
 int tfc_nl_ordering(const int64_t* edge_index, const int32_t* row_ptr, int64_t n_edges, int64_t n_nodes,
                     int32_t* src_eid, int32_t* src_nbr, int32_t* dst_eid, int32_t* dst_nbr, int32_t* status,
                     tfc_stream_t stream);

@@ -116,8 +116,8 @@ SIGNATURES = {
     "tfc_csr_build": (C.c_int, [_P, _P, _I64, _I64, _P, _P, _P, _P, _P, _P]),
     "tfc_segment_sum": (C.c_int, [_P, _P, _P, _I64, _I32, _P, _P]),
     "tfc_gather_rows": (C.c_int, [_P, _P, _I64, _I64, _I32, _P, _P]),
-    "tfc_nl_count": (C.c_int, [_P, _P, _P, _P, _P, _P, _I64, _I64, C.c_double, _P, _P]),
-    "tfc_nl_fill": (C.c_int, [_P, _P, _P, _P, _P, _P, _I64, _I64, C.c_double, _P, _I64, _P, _P, _P]),
+    "tfc_nl_count": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _I64, _I64, C.c_double, _P, _P]),
+    "tfc_nl_fill": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _I64, _I64, C.c_double, _P, _I64, _P, _P, _P]),
     "tfc_nl_ordering": (C.c_int, [_P, _P, _I64, _I64, _P, _P, _P, _P, _P, _P]),
     "tfc_conv_plan_create": (C.c_int, [C.POINTER(Path), _I32, _I32, _I32, _I32, _I32, C.POINTER(_P)]),
     "tfc_conv_plan_destroy": (C.c_int, [_P]),

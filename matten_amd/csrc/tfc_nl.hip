@@ -16,6 +16,8 @@
 
 namespace {
 
+constexpr int NL_MAX_IMAGES = 2048;  // per-wave LDS list of surviving images (4 waves: 32 KB); longer tables are not pruned
+
 struct NlArgs {
     const double* pos;         // [N,3]
     const int* node_graph;     // [N]
@@ -23,6 +25,7 @@ struct NlArgs {
     const int* shift_ptr;      // [G+1] first row of each graph's image table
     const int* shifts;         // [S_total,3] integer images, ascending lexicographic per graph
     const double* shift_vec;   // [S_total,3] = shifts @ cell, fp64 (host-computed)
+    const double* graph_box;   // [G,6] min xyz, max xyz of each graph's positions, or null (no pruning)
     long n_nodes;
     double r_max, r2_hi;
 };
@@ -53,23 +56,57 @@ template <bool FILL>
 __global__ __launch_bounds__(256) void tfc_nl_kernel(const NlArgs a, int* __restrict__ counts,
                                                      const int* __restrict__ row_ptr, long n_edges,
                                                      int64_t* __restrict__ edge_index, float* __restrict__ edge_shift) {
-    const int lane = threadIdx.x & 63;
-    const long wave0 = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    __shared__ int img[4][NL_MAX_IMAGES];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const long wave0 = (long)blockIdx.x * 4 + wv;
     for (long i = wave0; i < a.n_nodes; i += (long)gridDim.x * 4) {
         const int g = a.node_graph[i];
         const int n0 = a.graph_ptr[g], ng = a.graph_ptr[g + 1] - n0;
         const int s0 = a.shift_ptr[g], S = a.shift_ptr[g + 1] - s0;
         const double xi = a.pos[3 * i], yi = a.pos[3 * i + 1], zi = a.pos[3 * i + 2];
         if (S <= 0 || ng <= 0) continue;  // rejected on the host; counts stay 0
-        const long total = (long)ng * S;
-        // candidate c = j_local * S + s; (j, s) advance by 64 candidates per iteration
-        int j = lane / S, s = lane - j * S;
-        const int dj = 64 / S, ds = 64 - dj * S;
+        // Images that cannot hold a neighbour of i are dropped first: the box of the structure's
+        // positions, moved by the image vector, must come within r_max of pos[i] (with a relative margin
+        // far above rounding, so the test only ever removes candidates the exact test would reject).
+        // The survivors keep their ascending order in this wave's LDS list.
+        const bool pruned = a.graph_box != nullptr && S <= NL_MAX_IMAGES;
+        int Sp = S;
+        if (pruned) {
+            const double* bx = a.graph_box + 6L * g;
+            const double r2_box = a.r2_hi * (1.0 + 1e-9);
+            int cnt = 0;
+            for (int t0 = 0; t0 < S; t0 += 64) {
+                const int t = t0 + lane;
+                bool ok = false;
+                if (t < S) {
+                    const double* sv = a.shift_vec + 3L * (s0 + t);
+                    const double ex = fmax(fmax(bx[0] + sv[0] - xi, xi - (bx[3] + sv[0])), 0.0);
+                    const double ey = fmax(fmax(bx[1] + sv[1] - yi, yi - (bx[4] + sv[1])), 0.0);
+                    const double ez = fmax(fmax(bx[2] + sv[2] - zi, zi - (bx[5] + sv[2])), 0.0);
+                    ok = ex * ex + ey * ey + ez * ez <= r2_box;
+                }
+                const unsigned long long m = __ballot(ok);
+                if (ok) img[wv][cnt + __popcll(m & ((1ULL << lane) - 1ULL))] = t;
+                cnt += __popcll(m);
+            }
+            Sp = cnt;
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        }
+        if (Sp == 0) {
+            if (!FILL && lane == 0) counts[i + 1] = 0;
+            continue;
+        }
+        const long total = (long)ng * Sp;
+        // candidate c = j_local * Sp + t (t-th surviving image); (j, t) advance by 64 candidates per iteration
+        int j = lane / Sp, s = lane - j * Sp;
+        const int dj = 64 / Sp, ds = 64 - dj * Sp;
         int running = 0;
         const int base = FILL ? row_ptr[i] : 0;
         for (long c0 = 0; c0 < total; c0 += 64) {
             const bool valid = c0 + lane < total;
-            const bool keep = nl_keep(a, xi, yi, zi, n0 + (valid ? j : 0), s0 + (valid ? s : 0), n0 + j == i, valid);
+            const int srow = s0 + (valid ? (pruned ? img[wv][s] : s) : 0);
+            const bool keep = nl_keep(a, xi, yi, zi, n0 + (valid ? j : 0), srow, n0 + j == i, valid);
             const unsigned long long mask = __ballot(keep);
             if (FILL) {
                 if (keep) {
@@ -77,7 +114,7 @@ __global__ __launch_bounds__(256) void tfc_nl_kernel(const NlArgs a, int* __rest
                     if (p < n_edges) {
                         edge_index[p] = i;
                         edge_index[n_edges + p] = n0 + j;
-                        const int* sh = a.shifts + 3L * (s0 + s);
+                        const int* sh = a.shifts + 3L * srow;
                         edge_shift[3 * p] = (float)sh[0];
                         edge_shift[3 * p + 1] = (float)sh[1];
                         edge_shift[3 * p + 2] = (float)sh[2];
@@ -87,8 +124,8 @@ __global__ __launch_bounds__(256) void tfc_nl_kernel(const NlArgs a, int* __rest
             running += __popcll(mask);
             j += dj;
             s += ds;
-            if (s >= S) {
-                s -= S;
+            if (s >= Sp) {
+                s -= Sp;
                 ++j;
             }
         }
@@ -186,8 +223,9 @@ int nl_check(const double* pos, const int32_t* node_graph, const int32_t* graph_
 }  // namespace
 
 extern "C" int tfc_nl_count(const double* pos, const int32_t* node_graph, const int32_t* graph_ptr,
-                            const int32_t* shift_ptr, const int32_t* shifts, const double* shift_vec, int64_t n_nodes,
-                            int64_t n_graphs, double r_max, int32_t* row_ptr, tfc_stream_t stream_) {
+                            const int32_t* shift_ptr, const int32_t* shifts, const double* shift_vec,
+                            const double* graph_box, int64_t n_nodes, int64_t n_graphs, double r_max,
+                            int32_t* row_ptr, tfc_stream_t stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     const int rc = nl_check(pos, node_graph, graph_ptr, shift_ptr, shifts, shift_vec, n_nodes, n_graphs, r_max,
                             "tfc_nl_count");
@@ -195,7 +233,7 @@ extern "C" int tfc_nl_count(const double* pos, const int32_t* node_graph, const 
     TFC_REQUIRE(row_ptr, TFC_EINVAL, "tfc_nl_count: null output");
     TFC_HIP(hipMemsetAsync(row_ptr, 0, (size_t)(n_nodes + 1) * sizeof(int32_t), stream));
     if (n_nodes == 0) return TFC_OK;
-    const NlArgs a{pos, node_graph, graph_ptr, shift_ptr, shifts, shift_vec, (long)n_nodes, r_max,
+    const NlArgs a{pos, node_graph, graph_ptr, shift_ptr, shifts, shift_vec, graph_box, (long)n_nodes, r_max,
                    r_max * r_max * (1.0 + 1e-12)};
     const int grid = (int)std::min<long>((n_nodes + 3) / 4, 1 << 16);
     {
@@ -209,8 +247,9 @@ extern "C" int tfc_nl_count(const double* pos, const int32_t* node_graph, const 
 }
 
 extern "C" int tfc_nl_fill(const double* pos, const int32_t* node_graph, const int32_t* graph_ptr,
-                           const int32_t* shift_ptr, const int32_t* shifts, const double* shift_vec, int64_t n_nodes,
-                           int64_t n_graphs, double r_max, const int32_t* row_ptr, int64_t n_edges,
+                           const int32_t* shift_ptr, const int32_t* shifts, const double* shift_vec,
+                           const double* graph_box, int64_t n_nodes, int64_t n_graphs, double r_max,
+                           const int32_t* row_ptr, int64_t n_edges,
                            int64_t* edge_index, float* edge_shift, tfc_stream_t stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     const int rc = nl_check(pos, node_graph, graph_ptr, shift_ptr, shifts, shift_vec, n_nodes, n_graphs, r_max,
@@ -219,7 +258,7 @@ extern "C" int tfc_nl_fill(const double* pos, const int32_t* node_graph, const i
     TFC_REQUIRE(n_edges >= 0 && n_edges < (1LL << 31) - 1, TFC_EUNSUPPORTED, "tfc_nl_fill: bad edge count");
     if (n_nodes == 0 || n_edges == 0) return TFC_OK;
     TFC_REQUIRE(row_ptr && edge_index && edge_shift, TFC_EINVAL, "tfc_nl_fill: null tensor");
-    const NlArgs a{pos, node_graph, graph_ptr, shift_ptr, shifts, shift_vec, (long)n_nodes, r_max,
+    const NlArgs a{pos, node_graph, graph_ptr, shift_ptr, shifts, shift_vec, graph_box, (long)n_nodes, r_max,
                    r_max * r_max * (1.0 + 1e-12)};
     const int grid = (int)std::min<long>((n_nodes + 3) / 4, 1 << 16);
     TfcProfScope prof("tfc_nl_fill_kernel", stream);

@@ -19,7 +19,8 @@ from .. import _lib, ops
 from .neighbor import image_table
 
 
-def neighbor_list_batch(structures: Sequence[Dict[str, np.ndarray]], r_max: float, device, with_ordering: bool = True):
+def neighbor_list_batch(structures: Sequence[Dict[str, np.ndarray]], r_max: float, device, with_ordering: bool = True,
+                        prune_images: bool = True):
     """structures: dicts with `pos` [n,3], `cell` [3,3], optional `pbc` (default fully periodic).
     Returns a dict: `edge_index` [2,E] int64 (global node ids, offset as PyG's collate does),
     `edge_cell_shift` [E,3] float32, `num_neigh` [N] int64, `row_ptr` [N+1] int32, `ptr` [G+1] int64 and,
@@ -28,7 +29,7 @@ def neighbor_list_batch(structures: Sequence[Dict[str, np.ndarray]], r_max: floa
     if device.type != "cuda":
         raise RuntimeError("matten_amd: the GPU neighbour list needs a ROCm device (use data.neighbor.neighbor_list on the host)")
     r_max = float(r_max)
-    pos_l, node_graph, graph_ptr, shift_ptr, shifts_l, svec_l = [], [], [0], [0], [], []
+    pos_l, node_graph, graph_ptr, shift_ptr, shifts_l, svec_l, box_l = [], [], [0], [0], [], [], []
     for g, st in enumerate(structures):
         pos = np.asarray(st["pos"], dtype=np.float64).reshape(-1, 3)
         cell = np.asarray(st["cell"], dtype=np.float64).reshape(3, 3)
@@ -36,6 +37,7 @@ def neighbor_list_batch(structures: Sequence[Dict[str, np.ndarray]], r_max: floa
         pbc = (bool(pbc),) * 3 if isinstance(pbc, (bool, np.bool_)) else tuple(bool(b) for b in pbc)
         sh = image_table(pos, cell, pbc, r_max)
         pos_l.append(pos)
+        box_l.append(np.concatenate([pos.min(0), pos.max(0)]) if len(pos) else np.zeros(6))
         node_graph.append(np.full(len(pos), g, dtype=np.int32))
         graph_ptr.append(graph_ptr[-1] + len(pos))
         shifts_l.append(sh.astype(np.int32))
@@ -54,10 +56,11 @@ def neighbor_list_batch(structures: Sequence[Dict[str, np.ndarray]], r_max: floa
     sp_d = dev(np.array(shift_ptr), torch.int32)
     sh_d = dev(np.concatenate(shifts_l), torch.int32)
     sv_d = dev(np.concatenate(svec_l), torch.float64)
+    box_d = dev(np.stack(box_l), torch.float64) if prune_images else None
     row_ptr = torch.empty(N + 1, dtype=torch.int32, device=device)
     L = _lib.lib()
     with torch.cuda.device(device):
-        common = (ops._ptr(pos_d), ops._ptr(ng_d), ops._ptr(gp_d), ops._ptr(sp_d), ops._ptr(sh_d), ops._ptr(sv_d), N, G,
+        common = (ops._ptr(pos_d), ops._ptr(ng_d), ops._ptr(gp_d), ops._ptr(sp_d), ops._ptr(sh_d), ops._ptr(sv_d), ops._ptr(box_d), N, G,
                   C.c_double(r_max))
         _lib.check(L.tfc_nl_count(*common, ops._ptr(row_ptr), ops._stream()))
         rp_host = row_ptr.cpu().numpy()  # the one synchronisation

@@ -88,6 +88,9 @@ def test_random_triclinic_batch_against_bruteforce(device, pbc):
     assert np.array_equal(canon(ei, sh), canon(np.concatenate(ref_e, 1), np.concatenate(ref_s)))
     assert out["edge_index"].dtype == torch.int64 and out["edge_cell_shift"].dtype == torch.float32
     check_ordering(out, off)
+    # the image pruning (graph_box) only removes candidates the distance test would reject
+    full = neighbor_list_batch(structs, 3.7, device, with_ordering=False, prune_images=False)
+    assert torch.equal(full["edge_index"], out["edge_index"]) and torch.equal(full["edge_cell_shift"], out["edge_cell_shift"])
 
 
 def test_self_images_strict_cutoff_and_empty(device):
