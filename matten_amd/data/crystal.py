@@ -71,3 +71,29 @@ def collate(graphs: Sequence[Dict[str, np.ndarray]], device="cpu") -> Dict[str, 
 def synthetic_batch(n: int, a: float, batch: int, seed0: int = 1000, r_cut: float = 5.0, sigma: float = 0.05, device="cpu"):
     graphs = [make_crystal(n, a, sigma, r_cut, seed0 + g) for g in range(batch)]
     return collate(graphs, device), graphs
+
+
+def collate_gpu(graphs: Sequence[Dict[str, np.ndarray]], r_cut: float, device) -> Dict[str, torch.Tensor]:
+    """The same batch as `collate`, with the neighbour lists of all structures built on the device
+    in one go (`neighbor_gpu.neighbor_list_batch`, row f2) instead of being read from the graphs:
+    `graphs` need only `pos`, `cell`, `atomic_numbers` (and optionally `pbc`).  The edge groupings the
+    convolution layers need are derived from the list's symmetry and registered for the returned
+    `edge_index` tensor, so the layers do not sort it again.  Tensors equal `collate`'s bit for bit."""
+    from .neighbor_gpu import neighbor_list_batch
+
+    device = torch.device(device)
+    nl = neighbor_list_batch(graphs, r_cut, device)
+    sizes = [len(g["pos"]) for g in graphs]
+    out = {
+        K.POSITIONS: torch.as_tensor(np.concatenate([np.asarray(g["pos"], dtype=np.float64) for g in graphs]), dtype=torch.float32),
+        K.CELL: torch.as_tensor(np.concatenate([np.asarray(g["cell"], dtype=np.float64).reshape(3, 3) for g in graphs]), dtype=torch.float32),
+        K.ATOMIC_NUMBERS: torch.as_tensor(np.concatenate([np.asarray(g["atomic_numbers"]) for g in graphs]), dtype=torch.int64),
+        K.BATCH: torch.repeat_interleave(torch.arange(len(graphs), dtype=torch.int64), torch.tensor(sizes, dtype=torch.int64)),
+    }
+    out = {k: v.to(device) for k, v in out.items()}
+    out[K.EDGE_INDEX] = nl["edge_index"]
+    out[K.EDGE_CELL_SHIFT] = nl["edge_cell_shift"]
+    out["num_neigh"] = nl["num_neigh"].to(torch.float32)
+    out["ptr"] = nl["ptr"]
+    out["edge_ordering"] = nl["ordering"]  # keeps the registered ordering alive with the batch
+    return out

@@ -160,3 +160,34 @@ def test_ordering_flags_asymmetric_list(device):
     ref = ops.EdgeOrdering(ei.clone(), 3)
     for x, y in zip(o.by_dst + o.by_src, ref.by_dst + ref.by_src):
         assert torch.equal(x, y)
+
+
+def test_collate_gpu_equals_host_collate_and_layers_reuse_the_ordering(device):
+    """A batch assembled with the device neighbour list is tensor-for-tensor the host-collated batch,
+    and a conv stack run on either gives the same energies and forces bit for bit (same edge order,
+    same groupings: the summation orders are identical)."""
+    from matten_amd import keys as K, ops
+    from matten_amd.data.crystal import collate, collate_gpu, make_crystal
+
+    graphs = [make_crystal(3, 2.5, seed=40 + g) for g in range(3)]
+    a = collate(graphs, device)
+    b = collate_gpu([{k: g[k] for k in ("pos", "cell", "atomic_numbers")} for g in graphs], 5.0, device)
+    for k in (K.POSITIONS, K.CELL, K.ATOMIC_NUMBERS, K.EDGE_INDEX, K.EDGE_CELL_SHIFT, K.BATCH, "num_neigh", "ptr"):
+        assert a[k].dtype == b[k].dtype and torch.equal(a[k], b[k]), k
+    assert ops.edge_ordering(b[K.EDGE_INDEX], a[K.POSITIONS].shape[0]) is b["edge_ordering"]
+
+    import matten_amd.nn as H
+    from matten_amd.harness import ConvStack, species_index
+
+    torch.manual_seed(35)
+    model = ConvStack(H, 16, 2, "8x0e+8x1o+8x2e", 2, 16, 2, 5.0, 28.0).to(device)
+    outs = []
+    for batch in (a, b):
+        bb = {k: v for k, v in batch.items() if k != "edge_ordering"}
+        bb["species_index"] = species_index(bb[K.ATOMIC_NUMBERS])
+        pos = bb[K.POSITIONS].clone().requires_grad_(True)
+        bb[K.POSITIONS] = pos
+        _, energy, _ = model(bb, len(graphs))
+        (f,) = torch.autograd.grad(energy.sum(), pos)
+        outs.append((energy.detach().clone(), f.clone()))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
