@@ -522,7 +522,10 @@ def _gemm_workspace(n_floats: int) -> torch.Tensor:
 # The radial network of a layer depends on the edge embedding only, not on the node features: its
 # forward can run beside linear_1, and - because autograd runs a node's backward on the stream of
 # its forward - its backward (three MFMA-bound products per layer) runs beside the HBM-bound
-# convolution backward of the layer below.  TFC_MLP_SIDE_STREAM=0 keeps everything on one stream.
+# convolution backward of the layer below.  (The self connection, which depends on the layer's
+# input only, was tried there too: its products then share the CUs with the convolution backward,
+# which slows down by more than is gained - config 3: 3.71 -> 3.85 ms.)  TFC_MLP_SIDE_STREAM=0 keeps
+# everything on one stream.
 MLP_SIDE_STREAM = _os_environ.get("TFC_MLP_SIDE_STREAM", "1") != "0"
 _SIDE_STREAMS: "dict[int, torch.cuda.Stream]" = {}
 
@@ -601,7 +604,11 @@ def _ir_transpose(t: torch.Tensor, blocks) -> torch.Tensor:
     blocks = tuple(sorted(set(blocks)))
     key = (t.data_ptr(), t._version, n, d_row, blocks)
     hit = _TRANSPOSED.get(key)
+    cur = torch.cuda.current_stream(t.device)
     if hit is not None:
+        if hit[2] is not None and hit[3] != cur:  # made on another stream: order this one after it
+            cur.wait_event(hit[2])
+            hit[1].record_stream(cur)
         return hit[1]
     arr = (IrBlock * len(blocks))()
     for a, (off, mul, dim) in zip(arr, blocks):
@@ -610,7 +617,11 @@ def _ir_transpose(t: torch.Tensor, blocks) -> torch.Tensor:
     _lib.check(_lib.lib().tfc_ir_transpose(_ptr(t), n, d_row, arr, len(blocks), _ptr(out), _stream()))
     while len(_TRANSPOSED) >= 2:
         _TRANSPOSED.pop(next(iter(_TRANSPOSED)))
-    _TRANSPOSED[key] = (t.detach(), out)
+    ev = None
+    if MLP_SIDE_STREAM:  # the two consumers of a tensor may run on different streams
+        ev = torch.cuda.Event()
+        ev.record(cur)
+    _TRANSPOSED[key] = (t.detach(), out, ev, cur)
     return out
 
 
