@@ -420,6 +420,19 @@ int tfc_gate_fwd(const tfc_gate_seg* segs, int32_t n_segs, const float* x, int64
 int tfc_gate_bwd(const tfc_gate_seg* segs, int32_t n_segs, const float* x, const float* gout,
                  int64_t n_rows, int32_t d_in, int32_t d_out, float* dx, tfc_stream_t stream);
 
+/* Norm activation: the `activation_type="norm"` branch of ActivationLayer (eigenn/nn/utils.py:142-150),
+ * e3nn.nn.NormActivation(irreps_in, scalar_nonlinearity, normalize=True, epsilon=1e-8, bias=False):
+ * for every irrep copy u of a block, n = sqrt(max(sum_m x[u,m]^2, eps_squared)) (a clamped copy passes
+ * no gradient through n), out[u,m] = act(n) / n * x[u,m] (without `normalize`: act(n) * x[u,m]).
+ * One tfc_gate_seg per block of the row: in_off = out_off, count = mul, dim = 2l+1, act = TFC_ACT_*
+ * (applied as is - NormActivation does not rescale it), gate_off and cst unused.  Same irreps in and
+ * out: x, gout, out, dx are [n_rows, d].  eps_squared = 0: no clamp. */
+int tfc_norm_act_fwd(const tfc_gate_seg* segs, int32_t n_segs, const float* x, int64_t n_rows, int32_t d,
+                     float eps_squared, int32_t normalize, float* out, tfc_stream_t stream);
+int tfc_norm_act_bwd(const tfc_gate_seg* segs, int32_t n_segs, const float* x, const float* gout,
+                     int64_t n_rows, int32_t d, float eps_squared, int32_t normalize, float* dx,
+                     tfc_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------
  * Opt-in kernel timing (no counterpart in the reference, whose only timer is the epoch wall
  * clock, eigenn/model/utils.py:4-35).  While enabled, every main kernel launch is bracketed by

@@ -109,6 +109,75 @@ __global__ __launch_bounds__(256) void tfc_gate_bwd_kernel(const GateSegs g, con
     }
 }
 
+// Norm activation (e3nn.nn.NormActivation, eigenn/nn/utils.py:142-150): per irrep copy (u of a
+// block), n = sqrt(max(sum_m x^2, eps^2)), out = act(n) [/ n] * x.  One thread per column; the
+// 2l+1 values of its copy are re-read from cache.
+__device__ __forceinline__ bool norm_find(const GateSegs& g, int c, tfc_gate_seg& sg, int& base) {
+    for (int s = 0; s < g.n; ++s) {
+        const int idx = c - g.s[s].in_off;
+        if (idx >= 0 && idx < g.s[s].count * g.s[s].dim) {
+            sg = g.s[s];
+            base = sg.in_off + idx / sg.dim * sg.dim;
+            return true;
+        }
+    }
+    return false;
+}
+
+template <bool BWD>
+__global__ __launch_bounds__(256) void tfc_norm_act_kernel(const GateSegs g, const float* __restrict__ x,
+                                                           const float* __restrict__ gout, long n_rows, int d,
+                                                           float eps2, int normalize, float* __restrict__ out) {
+    const long total = n_rows * (long)d;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (long)gridDim.x * blockDim.x) {
+        const long r = i / d;
+        const int c = (int)(i - r * d);
+        tfc_gate_seg sg;
+        int base;
+        float v = 0.f;
+        if (norm_find(g, c, sg, base)) {
+            const float* xr = x + r * (long)d + base;
+            float n2 = 0.f, dot = 0.f;
+            for (int m = 0; m < sg.dim; ++m) {
+                n2 = fmaf(xr[m], xr[m], n2);
+                if (BWD) dot = fmaf(gout[r * (long)d + base + m], xr[m], dot);
+            }
+            const bool clamped = eps2 > 0.f && n2 < eps2;
+            // without epsilon e3nn takes the norm itself (its gradient at 0 is undefined there too)
+            const float n = sqrtf(clamped ? eps2 : n2);
+            const float a = act_eval(sg.act, n);
+            const float scale = normalize ? a / n : a;
+            if (!BWD) {
+                v = scale * x[i];
+            } else {
+                v = scale * gout[i];
+                if (!clamped) {
+                    const float da = act_grad(sg.act, n);
+                    // d scale / d n, times d n / d x[c] = x[c] / n
+                    const float ds = normalize ? (da * n - a) / (n * n) : da;
+                    v = fmaf(dot * ds / n, x[i], v);
+                }
+            }
+        }
+        out[i] = v;
+    }
+}
+
+int pack_norm_segs(const tfc_gate_seg* segs, int32_t n_segs, int32_t d, GateSegs* out) {
+    TFC_REQUIRE(segs && n_segs > 0 && n_segs <= MAX_SEGS, TFC_EINVAL, "tfc_norm_act: n_segs=%d outside 1..%d", n_segs,
+                MAX_SEGS);
+    for (int i = 0; i < n_segs; ++i) {
+        const tfc_gate_seg& s = segs[i];
+        TFC_REQUIRE(s.count >= 0 && s.dim >= 1 && s.dim <= 2 * TFC_LMAX + 1 && s.in_off >= 0 && s.in_off == s.out_off &&
+                        s.in_off + s.count * s.dim <= d && s.act >= TFC_ACT_IDENTITY && s.act <= TFC_ACT_SIGMOID,
+                    TFC_EINVAL, "tfc_norm_act: segment %d is inconsistent", i);
+        out->s[i] = s;
+    }
+    out->n = n_segs;
+    return TFC_OK;
+}
+
 int pack_segs(const tfc_gate_seg* segs, int32_t n_segs, int32_t d_in, int32_t d_out, GateSegs* out) {
     TFC_REQUIRE(segs && n_segs > 0 && n_segs <= MAX_SEGS, TFC_EINVAL, "tfc_gate: n_segs=%d outside 1..%d", n_segs,
                 MAX_SEGS);
@@ -156,5 +225,38 @@ extern "C" int tfc_gate_bwd(const tfc_gate_seg* segs, int32_t n_segs, const floa
     TfcProfScope prof("tfc_gate_bwd_kernel", stream);
     tfc_gate_bwd_kernel<<<grid, 256, 0, stream>>>(g, x, gout, (long)n_rows, d_in, d_out, dx);
     TFC_LAUNCH_CHECK("tfc_gate_bwd_kernel");
+    return TFC_OK;
+}
+
+extern "C" int tfc_norm_act_fwd(const tfc_gate_seg* segs, int32_t n_segs, const float* x, int64_t n_rows, int32_t d,
+                                float eps_squared, int32_t normalize, float* out, tfc_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    TFC_REQUIRE(n_rows >= 0 && d > 0 && eps_squared >= 0.f, TFC_EINVAL, "tfc_norm_act_fwd: bad size");
+    GateSegs g;
+    int rc = pack_norm_segs(segs, n_segs, d, &g);
+    if (rc) return rc;
+    if (n_rows == 0) return TFC_OK;
+    TFC_REQUIRE(x && out, TFC_EINVAL, "tfc_norm_act_fwd: null tensor");
+    const int grid = (int)std::min<long>((n_rows * (long)d + 255) / 256, 8192);
+    TfcProfScope prof("tfc_norm_act_fwd_kernel", stream);
+    tfc_norm_act_kernel<false><<<grid, 256, 0, stream>>>(g, x, nullptr, (long)n_rows, d, eps_squared, normalize, out);
+    TFC_LAUNCH_CHECK("tfc_norm_act_kernel<fwd>");
+    return TFC_OK;
+}
+
+extern "C" int tfc_norm_act_bwd(const tfc_gate_seg* segs, int32_t n_segs, const float* x, const float* gout,
+                                int64_t n_rows, int32_t d, float eps_squared, int32_t normalize, float* dx,
+                                tfc_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    TFC_REQUIRE(n_rows >= 0 && d > 0 && eps_squared >= 0.f, TFC_EINVAL, "tfc_norm_act_bwd: bad size");
+    GateSegs g;
+    int rc = pack_norm_segs(segs, n_segs, d, &g);
+    if (rc) return rc;
+    if (n_rows == 0) return TFC_OK;
+    TFC_REQUIRE(x && gout && dx, TFC_EINVAL, "tfc_norm_act_bwd: null tensor");
+    const int grid = (int)std::min<long>((n_rows * (long)d + 255) / 256, 8192);
+    TfcProfScope prof("tfc_norm_act_bwd_kernel", stream);
+    tfc_norm_act_kernel<true><<<grid, 256, 0, stream>>>(g, x, gout, (long)n_rows, d, eps_squared, normalize, dx);
+    TFC_LAUNCH_CHECK("tfc_norm_act_kernel<bwd>");
     return TFC_OK;
 }

@@ -27,7 +27,7 @@ def species_index(z: torch.Tensor) -> torch.Tensor:
 
 class ConvStack(torch.nn.Module):
     def __init__(self, modules, emb: int, lmax: int, conv_irreps: str, layers: int, hidden: int = 64, n_hidden: int = 2,
-                 r_cut: float = 5.0, avg_num_neighbors: float = 28.0, num_basis: int = 8):
+                 r_cut: float = 5.0, avg_num_neighbors: float = 28.0, num_basis: int = 8, activation_type: str = "gate"):
         super().__init__()
         M = modules
         self.embedding = torch.nn.Embedding(len(SPECIES_TABLE), emb)
@@ -44,7 +44,7 @@ class ConvStack(torch.nn.Module):
                 conv_layer_irreps=conv_irreps,
                 message_kwargs={"fc_num_hidden_layers": n_hidden, "fc_hidden_size": hidden},
                 update_kwargs={"use_self_connection": True, "avg_num_neighbors": avg_num_neighbors},
-                activation_type="gate",
+                activation_type=activation_type,
                 use_resnet=True,
             )
             self.convs.append(layer)

@@ -297,3 +297,41 @@ class UVUTensorProductCore(torch.nn.Module):
 
     def extra_repr(self):
         return f"{self.irreps_in1} x {self.irreps_in2} -> {self.irreps_out} | {len(self.instructions)} paths, {self.weight_numel} weights/edge"
+
+
+class NormActivation(torch.nn.Module):
+    """e3nn.nn.NormActivation(irreps_in, scalar_nonlinearity, normalize=True, epsilon=None, bias=False)
+    with the non-linearity given by name: every irrep copy is scaled by act(|x|) (divided by |x| when
+    `normalize`), |x| clamped from below at epsilon (a clamped copy passes no gradient through |x|).
+    Same irreps in and out.  The activation is applied as is (no second-moment rescaling), as e3nn
+    does here.  `bias=True` (a learnable shift of the norms) is not built: the reference passes
+    bias=False (eigenn/nn/utils.py:142-150)."""
+
+    def __init__(self, irreps_in, scalar_nonlinearity: str, normalize: bool = True, epsilon: Optional[float] = None, bias: bool = False):
+        super().__init__()
+        self.irreps_in = Irreps(irreps_in)
+        self.irreps_out = Irreps(irreps_in)
+        if epsilon is None and normalize:
+            epsilon = 1e-8  # e3nn's default when normalising
+        elif epsilon is not None and not normalize:
+            raise ValueError("epsilon and normalize = False don't make sense together")
+        if bias:
+            raise NotImplementedError("matten_amd NormActivation: bias=True is not built (the reference uses bias=False)")
+        if scalar_nonlinearity not in ACT:
+            raise ValueError(f"unknown activation `{scalar_nonlinearity}`")
+        self.scalar_nonlinearity = scalar_nonlinearity
+        self.normalize = bool(normalize)
+        self.epsilon = epsilon
+        self._eps_squared = 0.0 if epsilon is None else float(epsilon) * float(epsilon)
+        segs, off = [], 0
+        for mul, ir in self.irreps_in:
+            if mul > 0:
+                segs.append((off, off, mul, ir.dim, -1, ACT[scalar_nonlinearity], 1.0))
+            off += mul * ir.dim
+        self.spec = ops.GateSpec(d_in=self.irreps_in.dim, d_out=self.irreps_in.dim, segs=tuple(segs))
+
+    def forward(self, x):
+        return ops.norm_activation(x, self.spec, self._eps_squared, self.normalize)
+
+    def extra_repr(self):
+        return f"{self.irreps_in} | {self.scalar_nonlinearity}, normalize={self.normalize}, epsilon={self.epsilon}"

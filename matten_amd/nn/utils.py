@@ -9,7 +9,7 @@ import torch
 
 from .. import ops
 from ..irreps import Irrep, Irreps, tp_path_exists
-from .e3 import FullyConnectedNet, Gate, UVUTensorProductCore
+from .e3 import FullyConnectedNet, Gate, NormActivation, UVUTensorProductCore
 
 __all__ = ["ACTIVATION", "ActivationLayer", "UVUTensorProduct", "scatter_add", "tp_path_exists"]
 
@@ -72,9 +72,12 @@ class ActivationLayer(torch.nn.Module):
                 irreps_gated=irreps_gated,
             )
         elif activation_type == "norm":
-            raise NotImplementedError(
-                "matten_amd: activation_type='norm' (e3nn NormActivation) is outside the built hot path; "
-                "both target models use 'gate'"
+            self.activation = NormActivation(
+                irreps_in=(irreps_scalars + irreps_gated).simplify(),
+                scalar_nonlinearity=act_s[1],  # the norm is an even scalar (eigenn/nn/utils.py:146-147)
+                normalize=True,
+                epsilon=1e-8,
+                bias=False,
             )
         else:
             raise ValueError(f"Support `activation_type` includes ('gate', 'norm'), got {activation_type}")

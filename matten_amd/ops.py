@@ -37,6 +37,7 @@ __all__ = [
     "fctp",
     "GateSpec",
     "gate",
+    "norm_activation",
 ]
 
 
@@ -1094,3 +1095,33 @@ class _GateFn(torch.autograd.Function):
 
 def gate(x, spec: GateSpec):
     return _GateFn.apply(x, spec)
+
+
+class _NormActFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, spec: GateSpec, eps_squared: float, normalize: bool):
+        x = _f32(x, "x")
+        if x.shape[1] != spec.d_in:
+            raise ValueError(f"norm_activation: expected {spec.d_in} columns, got {x.shape[1]}")
+        out = torch.empty_like(x)
+        _lib.check(_lib.lib().tfc_norm_act_fwd(spec.c_array(), len(spec.segs), _ptr(x), x.shape[0], spec.d_in, eps_squared,
+                                               1 if normalize else 0, _ptr(out), _stream()))
+        ctx.save_for_backward(x)
+        ctx.args = (spec, eps_squared, normalize)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        (x,) = ctx.saved_tensors
+        spec, eps_squared, normalize = ctx.args
+        g = _f32(g, "grad_output")
+        dx = torch.empty_like(x)
+        _lib.check(_lib.lib().tfc_norm_act_bwd(spec.c_array(), len(spec.segs), _ptr(x), _ptr(g), x.shape[0], spec.d_in, eps_squared,
+                                               1 if normalize else 0, _ptr(dx), _stream()))
+        return dx, None, None, None
+
+
+def norm_activation(x, spec: GateSpec, eps_squared: float = 0.0, normalize: bool = True):
+    """e3nn.nn.NormActivation on [N, d] rows (tfc_norm_act_fwd/bwd); `spec.segs`: one
+    (in_off, in_off, mul, 2l+1, -1, act, 1.0) per block."""
+    return _NormActFn.apply(x, spec, float(eps_squared), bool(normalize))

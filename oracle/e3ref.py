@@ -667,3 +667,47 @@ def irreps_D(irreps, R: torch.Tensor, parity_of_R: int = 1) -> torch.Tensor:
             D = -D
         blocks.append(torch.kron(torch.eye(mul, dtype=torch.float64), D))
     return torch.block_diag(*blocks) if blocks else torch.zeros(0, 0, dtype=torch.float64)
+
+
+class NormActivation(torch.nn.Module):
+    """e3nn.nn.NormActivation(irreps_in, scalar_nonlinearity, normalize=True, epsilon=None, bias=False),
+    restated in e3nn's own op order (recollection of e3nn 0.4.x `e3nn/nn/_normact.py`; not under
+    /root/reference, PARITY UNPINNED like the rest of this file):
+        norms = o3.Norm(irreps_in, squared=(epsilon is not None))(x)        # per irrep copy
+        if epsilon: norms[norms < eps^2] = eps^2 (in place: no gradient through clamped entries); norms = sqrt(norms)
+        scalings = scalar_nonlinearity(norms [+ biases]);  if normalize: scalings = scalings / norms
+        out = o3.ElementwiseTensorProduct(norm irreps (0e per copy), irreps_in)(scalings, x)
+    The elementwise product 0e x l -> l with 'component' normalisation is a plain multiply
+    (sqrt(2l+1) * wigner_3j(0, l, l) = identity).  The non-linearity is applied as is (NormActivation
+    does not wrap it in normalize2mom).  bias=False only (what the reference passes)."""
+
+    def __init__(self, irreps_in, scalar_nonlinearity, normalize=True, epsilon=None, bias=False):
+        super().__init__()
+        self.irreps_in = Irreps(irreps_in)
+        self.irreps_out = Irreps(irreps_in)
+        if epsilon is None and normalize:
+            epsilon = 1e-8
+        elif epsilon is not None and not normalize:
+            raise ValueError("epsilon and normalize = False don't make sense together")
+        if bias:
+            raise NotImplementedError("oracle NormActivation: bias=True not restated")
+        self._eps_squared = 0.0 if epsilon is None else epsilon * epsilon
+        self.scalar_nonlinearity = scalar_nonlinearity
+        self.normalize = normalize
+
+    def forward(self, x):
+        cols = []
+        for (mul, ir), sl in zip(self.irreps_in, self.irreps_in.slices()):
+            if mul == 0:
+                continue
+            blk = x[:, sl].reshape(-1, mul, ir.dim)
+            norms = blk.pow(2).sum(-1) if self._eps_squared > 0 else blk.pow(2).sum(-1).sqrt()
+            if self._eps_squared > 0:
+                # masked in-place assignment: a constant where clamped (zero gradient), the value elsewhere
+                norms = torch.where(norms < self._eps_squared, torch.full_like(norms, self._eps_squared), norms)
+                norms = norms.sqrt()
+            scalings = self.scalar_nonlinearity(norms)
+            if self.normalize:
+                scalings = scalings / norms
+            cols.append((blk * scalings[:, :, None]).reshape(x.shape[0], -1))
+        return torch.cat(cols, dim=-1) if cols else x

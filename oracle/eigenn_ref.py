@@ -21,6 +21,7 @@ from .e3ref import (
     Irrep,
     Irreps,
     Linear,
+    NormActivation,
     TensorProduct,
     spherical_harmonics,
 )
@@ -222,7 +223,7 @@ def scatter_add(src, index, dim_size):
 
 
 class ActivationLayer(torch.nn.Module):
-    """eigenn/nn/utils.py:29-168 (gate branch; 'norm' is not on the target models' path)."""
+    """eigenn/nn/utils.py:29-168."""
 
     def __init__(self, tp_irreps_in1, tp_irreps_in2, tp_irreps_out, *, activation_type="gate", activation_scalars=None, activation_gates=None):
         super().__init__()
@@ -240,8 +241,17 @@ class ActivationLayer(torch.nn.Module):
         tp_irreps_out = ir_tmp.simplify()
         irreps_scalars = Irreps([(mul, ir) for mul, ir in tp_irreps_out if ir.l == 0 and tp_path_exists(tp_irreps_in1, tp_irreps_in2, ir)])
         irreps_gated = Irreps([(mul, ir) for mul, ir in tp_irreps_out if ir.l > 0 and tp_path_exists(tp_irreps_in1, tp_irreps_in2, ir)])
+        if activation_type == "norm":  # eigenn/nn/utils.py:142-150
+            self.activation = NormActivation(
+                irreps_in=(irreps_scalars + irreps_gated).simplify(),
+                scalar_nonlinearity=activation_scalars[1],
+                normalize=True,
+                epsilon=1e-8,
+                bias=False,
+            )
+            return
         if activation_type != "gate":
-            raise ValueError(f"Support `activation_type` includes ('gate',) in the oracle, got {activation_type}")
+            raise ValueError(f"Support `activation_type` includes ('gate', 'norm'), got {activation_type}")
         if irreps_gated.dim > 0:
             if tp_path_exists(tp_irreps_in1, tp_irreps_in2, "0e"):
                 ir = "0e"

@@ -36,6 +36,8 @@ CONFIGS = {
     "c3_lowrank": dict(emb=64, lmax=2, irreps="64x0o+64x0e+64x1o+64x1e+64x2o+64x2e", layers=2, hidden=64, nh=2, n=3, a=2.5, graphs=3),
     "c3_lowrank_nohint": dict(emb=64, lmax=2, irreps="64x0o+64x0e+32x1o+32x1e+16x2o+16x2e", layers=2, hidden=64, nh=2, n=3, a=2.5,
                               graphs=3, hint=False),
+    # activation_type="norm" (NormActivation instead of Gate, eigenn/nn/utils.py:142-150)
+    "norm_act": dict(emb=8, lmax=2, irreps="8x0o+8x0e+4x1o+4x1e+2x2o+2x2e", layers=2, hidden=16, nh=2, n=2, a=2.6, graphs=2, act="norm"),
     "c4": dict(emb=128, lmax=3, irreps="128x0o+128x0e+128x1o+128x1e+128x2o+128x2e+128x3o+128x3e", layers=2, hidden=64, nh=2, n=2, a=2.6, graphs=1),
 }
 R_CUT = 5.0
@@ -57,7 +59,8 @@ def Stack(impl, cfg):
         from oracle import eigenn_ref as M
     else:
         import matten_amd.nn as M
-    stack = ConvStack(M, cfg["emb"], cfg["lmax"], cfg["irreps"], cfg["layers"], cfg["hidden"], cfg["nh"], R_CUT, AVG_NEIGH)
+    stack = ConvStack(M, cfg["emb"], cfg["lmax"], cfg["irreps"], cfg["layers"], cfg["hidden"], cfg["nh"], R_CUT, AVG_NEIGH,
+                      activation_type=cfg.get("act", "gate"))
     stack.classes_hint = cfg.get("hint", True)
     return stack
 

@@ -799,3 +799,40 @@ def test_fctp_c_entry_points(device):
     assert L.tfc_fctp_bwd(ins, len(ins), P(xd), P(ad), P(wd), P(god), n, spec.d_x, spec.d_a, spec.d_out, wn, P(gt), 0,
                           None, None, P(da), None, None, None, 0, st) < 0
     assert L.tfc_fctp_fwd(ins, len(ins), P(xd), P(ad), P(wd), n, spec.d_x, spec.d_a, spec.d_out, wn - 1, 0, P(outd), None, 0, st) < 0
+
+
+# --------------------------------------------------------------------------------------- norm activation
+@pytest.mark.parametrize("act", ["ssp", "silu", "sigmoid"])
+@pytest.mark.parametrize("normalize", [True, False])
+def test_norm_activation_vs_oracle(device, act, normalize):
+    """tfc_norm_act_fwd/bwd against the oracle's NormActivation (e3nn op order), incl. all-zero copies
+    (clamped at epsilon: finite output, no gradient through the norm) and l up to 3."""
+    from matten_amd.nn.e3 import NormActivation
+    from oracle import e3ref as E
+    from oracle import eigenn_ref as R
+
+    irreps = "5x0e+3x0o+4x1o+2x1e+3x2e+2x3o"
+    eps = 1e-8 if normalize else None
+    hip = NormActivation(irreps, act, normalize=normalize, epsilon=eps)
+    ref = E.NormActivation(irreps, R.ACTIVATION["e"][act], normalize=normalize, epsilon=eps)
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(37, hip.irreps_in.dim, generator=g)
+    if normalize:
+        x[0] = 0.0  # every copy of this row is clamped
+        x[1, 8:11] = 0.0  # one 1o copy
+    go = torch.randn(37, hip.irreps_in.dim, generator=g)
+    xr = x.double().requires_grad_(True)
+    yr = ref(xr)
+    (gr,) = torch.autograd.grad(yr, xr, go.double())
+    xd = x.to(device).requires_grad_(True)
+    yd = hip(xd)
+    (gd,) = torch.autograd.grad(yd, xd, go.to(device))
+    assert torch.isfinite(yd).all() and torch.isfinite(gd).all()
+    # rows 0 and 1 hold clamped copies, whose scale act(1e-8) / 1e-8 is a cancellation in fp32 (ssp(1e-8)
+    # rounds to 0 there, in the reference's fp32 arithmetic too): those rows are compared with the oracle
+    # evaluated in fp32, the others with the fp64 value
+    assert rel(yd, yr) < TOL and rel(gd[2:], gr[2:]) < TOL
+    x32 = x.clone().requires_grad_(True)
+    (g32,) = torch.autograd.grad(ref(x32), x32, go)
+    assert rel(gd[:2], g32[:2]) < TOL
+    assert str(hip.irreps_out) == str(ref.irreps_out)

@@ -158,6 +158,21 @@ def test_constructor_error_conventions():
         H.ActivationLayer("4x0e", "0e+1o", "4x0e+4x1o", activation_type="nope")
 
 
+def test_activation_layer_norm_branch_matches_oracle():
+    """activation_type="norm" (eigenn/nn/utils.py:142-150): same irreps decisions as the oracle, and the
+    layer built with it publishes the same irreps and parameter shapes."""
+    for in1, in2, out in [("8x0e+4x1o", "0e+1o+2e", "8x0o+8x0e+4x1o+4x1e+2x2e"), ("4x0e", "0e+1o", "4x0e+4x1o+4x2e")]:
+        a = H.ActivationLayer(in1, in2, out, activation_type="norm")
+        b = R.ActivationLayer(in1, in2, out, activation_type="norm")
+        assert str(a.irreps_in) == str(b.irreps_in) and str(a.irreps_out) == str(b.irreps_out) == str(a.irreps_in)
+    irr = {K.NODE_FEATURES: "8x0e", K.NODE_ATTRS: "8x0e", K.EDGE_ATTRS: "0e+1o+2e", K.EDGE_EMBEDDING: "8x0e", K.EDGE_INDEX: None}
+    kw = dict(conv_layer_irreps="8x0o+8x0e+4x1o+4x1e", message_kwargs={"fc_num_hidden_layers": 1, "fc_hidden_size": 8},
+              update_kwargs={"use_self_connection": True, "avg_num_neighbors": 10.0}, activation_type="norm")
+    la, lb = H.PointConvMessagePassing(irreps_in=dict(irr), **kw), R.PointConvMessagePassing(irreps_in=dict(irr), **kw)
+    assert {k: str(v) for k, v in la.irreps_out.items()} == {k: str(v) for k, v in lb.irreps_out.items()}
+    assert {k: tuple(v.shape) for k, v in la.state_dict().items()} == {k: tuple(v.shape) for k, v in lb.state_dict().items()}
+
+
 def test_reference_constructor_smoke_test():
     """tests/nn/test_convolution.py:8-21 of the reference: the legacy PointConv constructs."""
     conv = H.PointConv(

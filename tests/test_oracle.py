@@ -239,3 +239,36 @@ def test_gradcheck_uvu_tensor_product():
     y = torch.randn(5, 9, dtype=torch.float64, requires_grad=True)
     e = torch.randn(5, 3, dtype=torch.float64, requires_grad=True)
     assert torch.autograd.gradcheck(lambda a, b, c: tp(a, b, c), (x, y, e), atol=1e-8)
+
+
+def test_norm_activation_oracle_properties():
+    """NormActivation restatement: acts on the norm of every irrep copy only (so it commutes with any
+    orthogonal map inside a copy), clamped copies stay finite and pass no gradient through the norm,
+    fp64 gradcheck away from zero."""
+    from oracle import e3ref as E
+    from oracle import eigenn_ref as R
+
+    irreps = E.Irreps("3x0e+2x1o+2x2e")
+    m = E.NormActivation(irreps, R.ACTIVATION["e"]["ssp"], normalize=True, epsilon=1e-8)
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(6, irreps.dim, dtype=torch.float64, generator=g)
+    y = m(x)
+    # an orthogonal map applied inside each copy commutes with the activation
+    q1, _ = torch.linalg.qr(torch.randn(3, 3, dtype=torch.float64, generator=g))
+    q2, _ = torch.linalg.qr(torch.randn(5, 5, dtype=torch.float64, generator=g))
+
+    def rot(t):
+        out = t.clone()
+        out[:, 3:9] = (t[:, 3:9].reshape(-1, 2, 3) @ q1.T).reshape(-1, 6)
+        out[:, 9:19] = (t[:, 9:19].reshape(-1, 2, 5) @ q2.T).reshape(-1, 10)
+        return out
+
+    assert torch.allclose(m(rot(x)), rot(y), atol=1e-12)
+    # norms of the outputs are |ssp(n)|, independent of direction
+    n_in = x[:, 3:6].norm(dim=1)
+    assert torch.allclose(y[:, 3:6].norm(dim=1), R.ACTIVATION["e"]["ssp"](n_in).abs(), atol=1e-12)
+    z = torch.zeros(2, irreps.dim, dtype=torch.float64, requires_grad=True)
+    yz = m(z)
+    (gz,) = torch.autograd.grad(yz.sum(), z)
+    assert torch.isfinite(yz).all() and torch.isfinite(gz).all()
+    assert torch.autograd.gradcheck(m, (x.clone().requires_grad_(True),))
