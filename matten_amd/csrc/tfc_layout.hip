@@ -22,22 +22,49 @@ struct Blocks {
     tfc_ir_block b[MAXB];
 };
 
+// One thread per (row n, channel u) of a block: it reads the 2l+1 consecutive values of that copy
+// (consecutive lanes read consecutive copies: one contiguous span per wave) and writes one value to
+// each of the 2l+1 planes (consecutive lanes write consecutive u: 256 contiguous bytes per wave and
+// plane).  blockIdx.y = block of the row.
+template <int DIM>
+__device__ __forceinline__ void ir_transpose_block(const tfc_ir_block b, const float* __restrict__ x, long n_rows,
+                                                   int d_row, float* __restrict__ out) {
+    const long total = n_rows * (long)b.mul;
+    const int dim = DIM > 0 ? DIM : b.dim;
+    float* ob = out + (long)b.off * n_rows;
+    for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long)gridDim.x * blockDim.x) {
+        long n;
+        int u;
+        if (total < (1L << 31)) {
+            const unsigned tt = (unsigned)t, q = tt / (unsigned)b.mul;
+            n = q;
+            u = (int)(tt - q * (unsigned)b.mul);
+        } else {
+            n = t / b.mul;
+            u = (int)(t - n * b.mul);
+        }
+        const float* src = x + n * (long)d_row + b.off + (long)u * dim;
+        if (DIM > 0) {
+            float v[DIM > 0 ? DIM : 1];
+#pragma unroll
+            for (int m = 0; m < DIM; ++m) v[m] = src[m];
+#pragma unroll
+            for (int m = 0; m < DIM; ++m) ob[((long)m * n_rows + n) * b.mul + u] = v[m];
+        } else {
+            for (int m = 0; m < dim; ++m) ob[((long)m * n_rows + n) * b.mul + u] = src[m];
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void tfc_ir_transpose_kernel(const Blocks bl, const float* __restrict__ x,
                                                                long n_rows, int d_row, float* __restrict__ out) {
-    const long total = n_rows * (long)d_row;
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
-         i += (long)gridDim.x * blockDim.x) {
-        const long n = i / d_row;
-        const int c = (int)(i - n * d_row);
-        for (int s = 0; s < bl.n; ++s) {
-            const tfc_ir_block b = bl.b[s];
-            const int idx = c - b.off;
-            if (idx >= 0 && idx < b.mul * b.dim) {
-                const int u = idx / b.dim, m = idx - u * b.dim;
-                out[(long)b.off * n_rows + ((long)m * n_rows + n) * b.mul + u] = x[i];
-                break;
-            }
-        }
+    const tfc_ir_block b = bl.b[blockIdx.y];
+    switch (b.dim) {
+        case 1: ir_transpose_block<1>(b, x, n_rows, d_row, out); break;
+        case 3: ir_transpose_block<3>(b, x, n_rows, d_row, out); break;
+        case 5: ir_transpose_block<5>(b, x, n_rows, d_row, out); break;
+        case 7: ir_transpose_block<7>(b, x, n_rows, d_row, out); break;
+        default: ir_transpose_block<0>(b, x, n_rows, d_row, out); break;
     }
 }
 
@@ -78,7 +105,9 @@ extern "C" int tfc_ir_transpose(const float* x, int64_t n_rows, int32_t d_row, c
     }
     if (n_rows == 0 || n_blocks == 0) return TFC_OK;
     TFC_REQUIRE(x && out, TFC_EINVAL, "tfc_ir_transpose: null tensor");
-    const int grid = (int)std::min<long>((n_rows * (long)d_row + 255) / 256, 8192);
+    int max_mul = 1;
+    for (int i = 0; i < n_blocks; ++i) max_mul = std::max(max_mul, bl.b[i].mul);
+    const dim3 grid((unsigned)std::min<long>((n_rows * (long)max_mul + 255) / 256, 4096), (unsigned)n_blocks);
     TfcProfScope prof("tfc_ir_transpose_kernel", stream);
     tfc_ir_transpose_kernel<<<grid, 256, 0, stream>>>(bl, x, (long)n_rows, d_row, out);
     TFC_LAUNCH_CHECK("tfc_ir_transpose_kernel");
