@@ -213,7 +213,8 @@ int tfc_conv_bwd_m(const tfc_conv_plan* plan, const float* x, const float* M, co
  * (:117-128, :63-78, :206-208) in one pass over the edges:
  *
  *   vec[e] = pos[ei[1,e]] - pos[ei[0,e]] + shift[e] @ cell[batch[ei[0,e]]]
- *   sh [e, l*l + m]  = Y_l^m(vec/|vec|), l = 0..lmax, component normalisation
+ *   sh [e, l*l + m]  = Y_l^m(vec/|vec|), l = 0..lmax, component normalisation; with sh_normalize = 0
+ *                      (edge_sh_normalize=False, _nequip.py:150,169) the same polynomials at vec itself
  *   emb[e, n]        = (2/r_max) sin(bw[n] |vec| / r_max) / |vec| * env_p(|vec| / r_max) * (|vec| < r_max)
  *
  * edge_index [2,E] int64; shift [E,3] (may be null: no periodic images); cell [G,3,3] (null iff
@@ -225,8 +226,8 @@ int tfc_conv_bwd_m(const tfc_conv_plan* plan, const float* x, const float* M, co
  */
 int tfc_edge_encode_fwd(const float* pos, const int64_t* edge_index, const float* shift,
                         const float* cell, const int64_t* batch, int64_t n_edges, int64_t n_nodes,
-                        int64_t n_graphs, int32_t lmax, const float* bw, int32_t n_basis,
-                        float r_max, float p, float* vec, float* len, float* sh, float* emb,
+                        int64_t n_graphs, int32_t lmax, int32_t sh_normalize, const float* bw,
+                        int32_t n_basis, float r_max, float p, float* vec, float* len, float* sh, float* emb,
                         tfc_stream_t stream);
 
 /* Backward: per-edge gradient of the edge vector from the gradients of sh and emb (either may
@@ -235,7 +236,7 @@ int tfc_edge_encode_fwd(const float* pos, const int64_t* edge_index, const float
  *   n_blocks = tfc_edge_bwd_blocks(E): the caller sums the rows (deterministic two-stage sum). */
 int64_t tfc_edge_bwd_blocks(int64_t n_edges);
 int tfc_edge_encode_bwd(const float* vec, const float* len, int64_t n_edges, int32_t lmax,
-                        const float* bw, int32_t n_basis, float r_max, float p, const float* dsh,
+                        int32_t sh_normalize, const float* bw, int32_t n_basis, float r_max, float p, const float* dsh,
                         const float* demb, const float* dvec_add, const float* dlen, float* dvec,
                         float* dbw_partial, tfc_stream_t stream);
 

@@ -95,7 +95,7 @@ __device__ __forceinline__ void sh_grad(int lmax, float x, float y, float z, con
 __global__ __launch_bounds__(256) void tfc_edge_fwd_kernel(
     const float* __restrict__ pos, const int64_t* __restrict__ ei, const float* __restrict__ shift,
     const float* __restrict__ cell, const int64_t* __restrict__ batch, long n_edges, long n_nodes, long n_graphs,
-    int lmax, const float* __restrict__ bw, int n_basis, float r_max, float p, float* vec,
+    int lmax, int sh_norm, const float* __restrict__ bw, int n_basis, float r_max, float p, float* vec,
     float* len, const float* len_in, float* __restrict__ sh, float* __restrict__ emb) {
     const int S = (lmax + 1) * (lmax + 1);
     for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < n_edges;
@@ -130,7 +130,8 @@ __global__ __launch_bounds__(256) void tfc_edge_fwd_kernel(
             if (!len_in && len) len[e] = r;
         }
         if (sh) {
-            const float inv = 1.f / fmaxf(r, 1e-12f);
+            // normalize=False (edge_sh_normalize): the same polynomials at the vector itself, Y_l(v) = |v|^l Y_l(v/|v|)
+            const float inv = sh_norm ? 1.f / fmaxf(r, 1e-12f) : 1.f;
             float o[16];
             sh_eval(lmax, vx * inv, vy * inv, vz * inv, o);
             float* so = sh + e * S;
@@ -153,7 +154,7 @@ constexpr int EDGE_BWD_BLOCK = 256;
 constexpr int MAX_BASIS = 64;
 
 __global__ __launch_bounds__(EDGE_BWD_BLOCK) void tfc_edge_bwd_kernel(
-    const float* __restrict__ vec, const float* __restrict__ len, long n_edges, int lmax,
+    const float* __restrict__ vec, const float* __restrict__ len, long n_edges, int lmax, int sh_norm,
     const float* __restrict__ bw, int n_basis, float r_max, float p, const float* __restrict__ dsh,
     const float* __restrict__ demb, const float* __restrict__ dvec_add, const float* __restrict__ dlen,
     float* __restrict__ dvec, float* __restrict__ dbw_partial) {
@@ -180,13 +181,20 @@ __global__ __launch_bounds__(EDGE_BWD_BLOCK) void tfc_edge_bwd_kernel(
                 const float* dr = dsh + e * S;
                 for (int q = 0; q < S; ++q) d[q] = dr[q];
                 float px, py, pz;
-                sh_grad(lmax, x, y, z, d, px, py, pz);
-                const float dot = px * x + py * y + pz * z;
-                // d n / d v = (I - n n^T) / |v|  (F.normalize; zero vectors stay zero)
-                const float k = r > 1e-12f ? inv : 0.f;
-                gx += (px - x * dot) * k;
-                gy += (py - y * dot) * k;
-                gz += (pz - z * dot) * k;
+                if (sh_norm) {
+                    sh_grad(lmax, x, y, z, d, px, py, pz);
+                    const float dot = px * x + py * y + pz * z;
+                    // d n / d v = (I - n n^T) / |v|  (F.normalize; zero vectors stay zero)
+                    const float k = r > 1e-12f ? inv : 0.f;
+                    gx += (px - x * dot) * k;
+                    gy += (py - y * dot) * k;
+                    gz += (pz - z * dot) * k;
+                } else {  // polynomials of the vector itself
+                    sh_grad(lmax, vx, vy, vz, d, px, py, pz);
+                    gx += px;
+                    gy += py;
+                    gz += pz;
+                }
             }
             if (demb) {
                 const float u = r / r_max;
@@ -264,8 +272,9 @@ __global__ __launch_bounds__(256) void tfc_edge_vec_bwd_kernel(const float* __re
 
 extern "C" int tfc_edge_encode_fwd(const float* pos, const int64_t* edge_index, const float* shift,
                                    const float* cell, const int64_t* batch, int64_t n_edges, int64_t n_nodes,
-                                   int64_t n_graphs, int32_t lmax, const float* bw, int32_t n_basis, float r_max,
-                                   float p, float* vec, float* len, float* sh, float* emb, tfc_stream_t stream_) {
+                                   int64_t n_graphs, int32_t lmax, int32_t sh_normalize, const float* bw,
+                                   int32_t n_basis, float r_max, float p, float* vec, float* len, float* sh,
+                                   float* emb, tfc_stream_t stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     TFC_REQUIRE(n_edges >= 0 && n_nodes >= 0, TFC_EINVAL, "tfc_edge_encode_fwd: negative size");
     if (n_edges == 0) return TFC_OK;
@@ -280,7 +289,7 @@ extern "C" int tfc_edge_encode_fwd(const float* pos, const int64_t* edge_index, 
     const int grid = (int)std::min<long>((n_edges + 255) / 256, 8192);
     TfcProfScope prof("tfc_edge_fwd_kernel", stream);
     tfc_edge_fwd_kernel<<<grid, 256, 0, stream>>>(pos, edge_index, shift, cell, batch, (long)n_edges,
-                                                  (long)n_nodes, (long)n_graphs, sh ? lmax : 0, bw, n_basis,
+                                                  (long)n_nodes, (long)n_graphs, sh ? lmax : 0, sh_normalize, bw, n_basis,
                                                   r_max, p, vec, pos ? len : nullptr, pos ? nullptr : len, sh,
                                                   emb);
     TFC_LAUNCH_CHECK("tfc_edge_fwd_kernel");
@@ -293,7 +302,7 @@ extern "C" int64_t tfc_edge_bwd_blocks(int64_t n_edges) {
 }
 
 extern "C" int tfc_edge_encode_bwd(const float* vec, const float* len, int64_t n_edges, int32_t lmax,
-                                   const float* bw, int32_t n_basis, float r_max, float p, const float* dsh,
+                                   int32_t sh_normalize, const float* bw, int32_t n_basis, float r_max, float p, const float* dsh,
                                    const float* demb, const float* dvec_add, const float* dlen, float* dvec,
                                    float* dbw_partial, tfc_stream_t stream_) {
     hipStream_t stream = (hipStream_t)stream_;
@@ -310,7 +319,7 @@ extern "C" int tfc_edge_encode_bwd(const float* vec, const float* len, int64_t n
     }
     TFC_REQUIRE(vec && dvec, TFC_EINVAL, "tfc_edge_encode_bwd: null tensor");
     TfcProfScope prof("tfc_edge_bwd_kernel", stream);
-    tfc_edge_bwd_kernel<<<grid, EDGE_BWD_BLOCK, 0, stream>>>(vec, len, (long)n_edges, dsh ? lmax : 0, bw, n_basis,
+    tfc_edge_bwd_kernel<<<grid, EDGE_BWD_BLOCK, 0, stream>>>(vec, len, (long)n_edges, dsh ? lmax : 0, sh_normalize, bw, n_basis,
                                                              r_max, p, dsh, demb, dvec_add, dlen, dvec,
                                                              dbw_partial);
     TFC_LAUNCH_CHECK("tfc_edge_bwd_kernel");

@@ -125,7 +125,8 @@ _SH_FACTOR = {
 
 
 class SphericalHarmonicEdgeAttrs(ModuleIrreps, torch.nn.Module):
-    """eigenn/nn/_nequip.py:132-176.  EDGE_ATTRS = Y_l^m of the unit edge vector."""
+    """eigenn/nn/_nequip.py:132-176.  EDGE_ATTRS = Y_l^m of the unit edge vector (of the edge vector
+    itself with `edge_sh_normalize=False`)."""
 
     def __init__(
         self,
@@ -146,8 +147,7 @@ class SphericalHarmonicEdgeAttrs(ModuleIrreps, torch.nn.Module):
                 raise ValueError(f"spherical harmonics irreps must have parity (-1)^l, got {self.irreps_edge_sh}")
         if edge_sh_normalization not in _SH_FACTOR:
             raise ValueError(f"unknown normalization {edge_sh_normalization}")
-        if not edge_sh_normalize:
-            raise NotImplementedError("matten_amd: edge_sh_normalize=False is outside the built hot path")
+        self.normalize = bool(edge_sh_normalize)
         self.init_irreps(irreps_in=irreps_in, irreps_out={out_field: self.irreps_edge_sh})
         self.lmax = self.irreps_edge_sh.lmax
         if self.lmax > 3:
@@ -165,8 +165,10 @@ class SphericalHarmonicEdgeAttrs(ModuleIrreps, torch.nn.Module):
         self.register_buffer("_scale", torch.tensor(scale, dtype=torch.float32), persistent=False)
 
     def forward(self, data: DataKey.Type) -> DataKey.Type:
+        if not self.normalize and DataKey.EDGE_VECTORS not in data:
+            data = with_edge_vectors(data, with_lengths=False)
         if DataKey.EDGE_VECTORS in data:
-            sh = ops.spherical_harmonics(data[DataKey.EDGE_VECTORS], self.lmax)
+            sh = ops.spherical_harmonics(data[DataKey.EDGE_VECTORS], self.lmax, self.normalize)
         else:
             data = with_edge_vectors(data, with_lengths=False, _lmax=self.lmax)
             sh = data.pop("_tfc_sh_full")

@@ -343,7 +343,7 @@ class _EdgeGeometryFn(torch.autograd.Function):
     """pos (+ periodic shifts) -> edge vectors, lengths and, optionally, spherical harmonics."""
 
     @staticmethod
-    def forward(ctx, pos, shift, cell, batch, ordering: EdgeOrdering, lmax: int):
+    def forward(ctx, pos, shift, cell, batch, ordering: EdgeOrdering, lmax: int, sh_normalize: bool = True):
         pos = _f32(pos, "pos")
         ei = ordering.edge_index
         E, N = ordering.n_edges, pos.shape[0]
@@ -366,12 +366,12 @@ class _EdgeGeometryFn(torch.autograd.Function):
         if E:
             _lib.check(
                 _lib.lib().tfc_edge_encode_fwd(
-                    _ptr(pos), _ptr(ei), _ptr(shift), _ptr(cell), _ptr(batch), E, N, G, max(lmax, 0), None, 0,
+                    _ptr(pos), _ptr(ei), _ptr(shift), _ptr(cell), _ptr(batch), E, N, G, max(lmax, 0), 1 if sh_normalize else 0, None, 0,
                     1.0, 6.0, _ptr(vec), _ptr(length), _ptr(sh), None, _stream(),
                 )
             )
         ctx.save_for_backward(vec, length)
-        ctx.ordering, ctx.lmax = ordering, lmax
+        ctx.ordering, ctx.lmax, ctx.sh_normalize = ordering, lmax, bool(sh_normalize)
         ctx.set_materialize_grads(False)
         if sh is None:
             return vec, length
@@ -385,28 +385,28 @@ class _EdgeGeometryFn(torch.autograd.Function):
         if E:
             _lib.check(
                 _lib.lib().tfc_edge_encode_bwd(
-                    _ptr(vec), _ptr(length), E, max(ctx.lmax, 0), None, 0, 1.0, 6.0,
+                    _ptr(vec), _ptr(length), E, max(ctx.lmax, 0), 1 if ctx.sh_normalize else 0, None, 0, 1.0, 6.0,
                     _ptr(_f32(dsh, "dsh")) if dsh is not None else None, None,
                     _ptr(_f32(dvec_in, "dvec")) if dvec_in is not None else None,
                     _ptr(_f32(dlen, "dlen")) if dlen is not None else None, _ptr(dvec), None, _stream(),
                 )
             )
-        return _dvec_to_dpos(dvec, ctx.ordering), None, None, None, None, None
+        return _dvec_to_dpos(dvec, ctx.ordering), None, None, None, None, None, None
 
 
-def edge_geometry(pos, ordering: EdgeOrdering, shift=None, cell=None, batch=None, lmax: int = -1):
+def edge_geometry(pos, ordering: EdgeOrdering, shift=None, cell=None, batch=None, lmax: int = -1, sh_normalize: bool = True):
     """(vec, len) or (vec, len, sh) from positions; differentiable w.r.t. `pos`.  (The
     reference's graph is also differentiable w.r.t. `cell`; that gradient is not provided.)"""
     if cell is not None and cell.requires_grad:
         raise NotImplementedError("matten_amd: gradient with respect to `cell` is not implemented")
-    return _EdgeGeometryFn.apply(pos, shift, cell, batch, ordering, lmax)
+    return _EdgeGeometryFn.apply(pos, shift, cell, batch, ordering, lmax, sh_normalize)
 
 
 class _ShFn(torch.autograd.Function):
     """Spherical harmonics of caller-supplied edge vectors."""
 
     @staticmethod
-    def forward(ctx, vec, lmax: int):
+    def forward(ctx, vec, lmax: int, normalize: bool = True):
         vec = _f32(vec, "edge_vectors")
         E = vec.shape[0]
         sh = torch.empty(E, (lmax + 1) ** 2, dtype=torch.float32, device=vec.device)
@@ -414,12 +414,12 @@ class _ShFn(torch.autograd.Function):
             # len = null: the kernel takes the lengths from the vectors themselves
             _lib.check(
                 _lib.lib().tfc_edge_encode_fwd(
-                    None, None, None, None, None, E, 0, 1, lmax, None, 0, 1.0, 6.0, _ptr(vec), None, _ptr(sh),
-                    None, _stream(),
+                    None, None, None, None, None, E, 0, 1, lmax, 1 if normalize else 0, None, 0, 1.0, 6.0, _ptr(vec), None,
+                    _ptr(sh), None, _stream(),
                 )
             )
         ctx.save_for_backward(vec)
-        ctx.lmax = lmax
+        ctx.lmax, ctx.normalize = lmax, bool(normalize)
         return sh
 
     @staticmethod
@@ -429,15 +429,15 @@ class _ShFn(torch.autograd.Function):
         if vec.shape[0]:
             _lib.check(
                 _lib.lib().tfc_edge_encode_bwd(
-                    _ptr(vec), None, vec.shape[0], ctx.lmax, None, 0, 1.0, 6.0, _ptr(_f32(dsh, "dsh")), None,
-                    None, None, _ptr(dvec), None, _stream(),
+                    _ptr(vec), None, vec.shape[0], ctx.lmax, 1 if ctx.normalize else 0, None, 0, 1.0, 6.0,
+                    _ptr(_f32(dsh, "dsh")), None, None, None, _ptr(dvec), None, _stream(),
                 )
             )
-        return dvec, None
+        return dvec, None, None
 
 
-def spherical_harmonics(vec, lmax: int):
-    return _ShFn.apply(vec, lmax)
+def spherical_harmonics(vec, lmax: int, normalize: bool = True):
+    return _ShFn.apply(vec, lmax, normalize)
 
 
 class _RadialFn(torch.autograd.Function):
@@ -452,7 +452,7 @@ class _RadialFn(torch.autograd.Function):
         if E:
             _lib.check(
                 _lib.lib().tfc_edge_encode_fwd(
-                    None, None, None, None, None, E, 0, 1, 0, _ptr(bw), B, float(r_max), float(p), _ptr(vec),
+                    None, None, None, None, None, E, 0, 1, 0, 1, _ptr(bw), B, float(r_max), float(p), _ptr(vec),
                     _ptr(length), None, _ptr(emb), _stream(),
                 )
             )
@@ -472,7 +472,7 @@ class _RadialFn(torch.autograd.Function):
         part = torch.empty(nb, B, dtype=torch.float32, device=vec.device) if ctx.needs_input_grad[2] else None
         _lib.check(
             _lib.lib().tfc_edge_encode_bwd(
-                _ptr(vec), _ptr(length), E, 0, _ptr(bw), B, ctx.r_max, ctx.p, None, _ptr(_f32(demb, "demb")), None,
+                _ptr(vec), _ptr(length), E, 0, 1, _ptr(bw), B, ctx.r_max, ctx.p, None, _ptr(_f32(demb, "demb")), None,
                 None, _ptr(dvec), _ptr(part), _stream(),
             )
         )

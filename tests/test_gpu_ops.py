@@ -836,3 +836,28 @@ def test_norm_activation_vs_oracle(device, act, normalize):
     (g32,) = torch.autograd.grad(ref(x32), x32, go)
     assert rel(gd[:2], g32[:2]) < TOL
     assert str(hip.irreps_out) == str(ref.irreps_out)
+
+
+@pytest.mark.parametrize("lmax", [1, 2, 3])
+@pytest.mark.parametrize("normalization", ["component", "integral", "norm"])
+def test_spherical_harmonics_without_normalising_the_vector(device, lmax, normalization):
+    """edge_sh_normalize=False (eigenn/nn/_nequip.py:150,169): the polynomials at the edge vector itself,
+    value and gradient against the oracle, through the module (positions -> EDGE_ATTRS -> d/dpos)."""
+    import matten_amd.nn as H
+    from matten_amd import keys as K
+    from oracle import eigenn_ref as R
+
+    g = torch.Generator().manual_seed(lmax)
+    pos = torch.randn(12, 3, generator=g) * 1.5
+    ei = torch.randint(0, 12, (2, 50), generator=g)
+    ei = ei[:, ei[0] != ei[1]]
+    go = torch.randn(ei.shape[1], (lmax + 1) ** 2, generator=g)
+    outs = []
+    for mod, dev, dt in ((R, "cpu", torch.float64), (H, device, torch.float32)):
+        m = mod.SphericalHarmonicEdgeAttrs(lmax, edge_sh_normalization=normalization, edge_sh_normalize=False)
+        p = pos.to(dev, dt).requires_grad_(True)
+        data = m({K.POSITIONS: p, K.EDGE_INDEX: ei.to(dev)})
+        sh = data[K.EDGE_ATTRS]
+        (gp,) = torch.autograd.grad(sh, p, go.to(dev, dt))
+        outs.append((sh.detach(), gp))
+    assert rel(outs[1][0], outs[0][0]) < TOL and rel(outs[1][1], outs[0][1]) < TOL
