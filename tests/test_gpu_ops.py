@@ -854,7 +854,7 @@ def test_spherical_harmonics_without_normalising_the_vector(device, lmax, normal
     go = torch.randn(ei.shape[1], (lmax + 1) ** 2, generator=g)
     outs = []
     for mod, dev, dt in ((R, "cpu", torch.float64), (H, device, torch.float32)):
-        m = mod.SphericalHarmonicEdgeAttrs(lmax, edge_sh_normalization=normalization, edge_sh_normalize=False)
+        m = mod.SphericalHarmonicEdgeAttrs(lmax, edge_sh_normalization=normalization, edge_sh_normalize=False).to(dev)
         p = pos.to(dev, dt).requires_grad_(True)
         data = m({K.POSITIONS: p, K.EDGE_INDEX: ei.to(dev)})
         sh = data[K.EDGE_ATTRS]
