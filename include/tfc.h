@@ -248,6 +248,13 @@ int tfc_edge_vec_bwd(const float* dvec, const int32_t* rp_src, const int32_t* ei
                      const int32_t* rp_dst, const int32_t* eid_dst, int64_t n_nodes, float* dpos,
                      tfc_stream_t stream);
 
+/* Gradient of the periodic cell (with_edge_vectors is differentiable in `cell` too, _nequip.py:236-262):
+ *   part[n][3a+b] = sum_{e: ei[0,e]=n} shift[e][a] * dvec[e][b]      part [N,9]
+ * per sender node, in ascending edge id; the caller sums the rows of each structure's nodes
+ * (tfc_csr_build over `batch` + tfc_segment_sum) to get dcell [G,3,3].  No atomics. */
+int tfc_edge_cell_bwd(const float* dvec, const float* shift, const int32_t* rp_src, const int32_t* eid_src,
+                      int64_t n_nodes, float* part, tfc_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------
  * Dense contractions on the fp32 matrix cores (v_mfma_f32_32x32x2_f32: exact fp32 fmaf chains).
  *

@@ -134,6 +134,7 @@ SIGNATURES = {
     "tfc_edge_bwd_blocks": (_I64, [_I64]),
     "tfc_edge_encode_bwd": (C.c_int, [_P, _P, _I64, _I32, _I32, _P, _I32, _F, _F, _P, _P, _P, _P, _P, _P, _P]),
     "tfc_edge_vec_bwd": (C.c_int, [_P, _P, _P, _P, _P, _I64, _P, _P]),
+    "tfc_edge_cell_bwd": (C.c_int, [_P, _P, _P, _P, _I64, _P, _P]),
     "tfc_gemm": (C.c_int, [C.POINTER(GemmDesc), _P]),
     "tfc_gemm_group": (C.c_int, [C.POINTER(GemmDesc), _I32, _P]),
     "tfc_gemm_workspace_floats": (_I64, [_I64, _I64, _I64]),

@@ -326,6 +326,38 @@ extern "C" int tfc_edge_encode_bwd(const float* vec, const float* len, int64_t n
     return TFC_OK;
 }
 
+// part[n][3 a + b] = sum_{e: ei[0,e] = n} shift[e][a] * dvec[e][b]: the sender's share of d/dcell of
+// vec[e] = ... + shift[e] @ cell[batch[ei[0,e]]]; fixed order (ascending edge id), no atomics
+__global__ __launch_bounds__(256) void tfc_edge_cell_bwd_kernel(const float* __restrict__ dvec,
+                                                                const float* __restrict__ shift,
+                                                                const int* __restrict__ rp_src,
+                                                                const int* __restrict__ eid_src, long n_nodes,
+                                                                float* __restrict__ part) {
+    const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long n = t / 9;
+    const int c = (int)(t - 9 * n), a = c / 3, b = c - 3 * a;
+    if (n >= n_nodes) return;
+    float s = 0.f;
+    for (int k = rp_src[n]; k < rp_src[n + 1]; ++k) {
+        const long e = eid_src[k];
+        s = fmaf(shift[3 * e + a], dvec[3 * e + b], s);
+    }
+    part[9 * n + c] = s;
+}
+
+extern "C" int tfc_edge_cell_bwd(const float* dvec, const float* shift, const int32_t* rp_src, const int32_t* eid_src,
+                                 int64_t n_nodes, float* part, tfc_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    TFC_REQUIRE(n_nodes >= 0, TFC_EINVAL, "tfc_edge_cell_bwd: negative size");
+    if (n_nodes == 0) return TFC_OK;
+    TFC_REQUIRE(dvec && shift && rp_src && eid_src && part, TFC_EINVAL, "tfc_edge_cell_bwd: null tensor");
+    const long t = 9 * (long)n_nodes;
+    tfc_edge_cell_bwd_kernel<<<(unsigned)((t + 255) / 256), 256, 0, stream>>>(dvec, shift, rp_src, eid_src,
+                                                                              (long)n_nodes, part);
+    TFC_LAUNCH_CHECK("tfc_edge_cell_bwd_kernel");
+    return TFC_OK;
+}
+
 extern "C" int tfc_edge_vec_bwd(const float* dvec, const int32_t* rp_src, const int32_t* eid_src,
                                 const int32_t* rp_dst, const int32_t* eid_dst, int64_t n_nodes, float* dpos,
                                 tfc_stream_t stream_) {

@@ -339,6 +339,30 @@ def _dvec_to_dpos(dvec, ordering: EdgeOrdering):
     return dpos
 
 
+def _dvec_to_dcell(dvec, shift, batch, n_graphs: int, ordering: EdgeOrdering):
+    """dcell [G,3,3] = sum over the edges of each structure of shift[e]^T dvec[e]: per sender node
+    (tfc_edge_cell_bwd), then over the nodes of each structure (tfc_csr_build + tfc_segment_sum)."""
+    dev = dvec.device
+    N = ordering.n_nodes
+    part = torch.empty(N, 9, dtype=torch.float32, device=dev)
+    rps, eids, _ = ordering.by_src
+    L = _lib.lib()
+    _lib.check(L.tfc_edge_cell_bwd(_ptr(dvec), _ptr(shift), _ptr(rps), _ptr(eids), N, _ptr(part), _stream()))
+    if n_graphs == 1:
+        rp = torch.tensor([0, N], dtype=torch.int32, device=dev)
+        nid = torch.arange(max(N, 1), dtype=torch.int32, device=dev)
+    else:
+        rp = torch.empty(n_graphs + 1, dtype=torch.int32, device=dev)
+        nid = torch.empty(max(N, 1), dtype=torch.int32, device=dev)
+        other = torch.empty(max(N, 1), dtype=torch.int32, device=dev)
+        status = torch.zeros(1, dtype=torch.int32, device=dev)
+        ws = torch.empty(max(int(L.tfc_csr_workspace_bytes(n_graphs, N)), 8), dtype=torch.uint8, device=dev)
+        _lib.check(L.tfc_csr_build(_ptr(batch), _ptr(batch), N, n_graphs, _ptr(rp), _ptr(nid), _ptr(other), _ptr(status), _ptr(ws), _stream()))
+    dcell = torch.empty(n_graphs, 9, dtype=torch.float32, device=dev)
+    _lib.check(L.tfc_segment_sum(_ptr(part), _ptr(rp), _ptr(nid), n_graphs, 9, _ptr(dcell), _stream()))
+    return dcell.view(n_graphs, 3, 3)
+
+
 class _EdgeGeometryFn(torch.autograd.Function):
     """pos (+ periodic shifts) -> edge vectors, lengths and, optionally, spherical harmonics."""
 
@@ -371,6 +395,7 @@ class _EdgeGeometryFn(torch.autograd.Function):
                 )
             )
         ctx.save_for_backward(vec, length)
+        ctx.cell_args = (shift, batch, G, cell.shape) if shift is not None else None
         ctx.ordering, ctx.lmax, ctx.sh_normalize = ordering, lmax, bool(sh_normalize)
         ctx.set_materialize_grads(False)
         if sh is None:
@@ -391,14 +416,18 @@ class _EdgeGeometryFn(torch.autograd.Function):
                     _ptr(_f32(dlen, "dlen")) if dlen is not None else None, _ptr(dvec), None, _stream(),
                 )
             )
-        return _dvec_to_dpos(dvec, ctx.ordering), None, None, None, None, None, None
+        dcell = None
+        if ctx.needs_input_grad[2] and ctx.cell_args is not None:
+            shift, batch, G, _ = ctx.cell_args
+            dcell = _dvec_to_dcell(dvec, shift, batch, G, ctx.ordering) if E else torch.zeros(G, 3, 3, dtype=torch.float32, device=vec.device)
+        return _dvec_to_dpos(dvec, ctx.ordering), None, dcell, None, None, None, None
 
 
 def edge_geometry(pos, ordering: EdgeOrdering, shift=None, cell=None, batch=None, lmax: int = -1, sh_normalize: bool = True):
-    """(vec, len) or (vec, len, sh) from positions; differentiable w.r.t. `pos`.  (The
-    reference's graph is also differentiable w.r.t. `cell`; that gradient is not provided.)"""
-    if cell is not None and cell.requires_grad:
-        raise NotImplementedError("matten_amd: gradient with respect to `cell` is not implemented")
+    """(vec, len) or (vec, len, sh) from positions; differentiable w.r.t. `pos` and, as the
+    reference's graph is (eigenn/nn/_nequip.py:236-262), w.r.t. `cell` ([G,3,3])."""
+    if cell is not None:
+        cell = cell.reshape(-1, 3, 3)
     return _EdgeGeometryFn.apply(pos, shift, cell, batch, ordering, lmax, sh_normalize)
 
 
