@@ -16,6 +16,8 @@ from __future__ import annotations
 
 from typing import Dict, Optional
 
+import weakref
+
 import torch
 
 from .. import keys as DataKey
@@ -39,6 +41,23 @@ def compile_mode(mode: str):
         return cls
 
     return deco
+
+
+# Prefetch state of the side-stream radial networks, kept outside the modules (they stay picklable
+# and deep-copyable): which layer used the same embedding tensor right after which (learnt from the
+# previous pass), and the weights a layer's predecessor has already computed for it.
+_LAST_RADIAL = [None, None]  # (layer weakref, embedding key) of the most recent side-stream radial network
+_NEXT_ON_EMBEDDING = weakref.WeakKeyDictionary()  # layer -> weakref of its successor
+_PREFETCHED = weakref.WeakKeyDictionary()  # layer -> (key, embedding, weights, event)
+
+
+def _note_radial_chain(layer, key):
+    prev, prev_key = _LAST_RADIAL
+    if prev is not None and prev_key == key:
+        p = prev()
+        if p is not None and p is not layer:
+            _NEXT_ON_EMBEDDING[p] = weakref.ref(layer)
+    _LAST_RADIAL[0], _LAST_RADIAL[1] = weakref.ref(layer), key
 
 
 class PointConvMessage(ModuleIrreps, torch.nn.Module):
@@ -66,19 +85,38 @@ class PointConvMessage(ModuleIrreps, torch.nn.Module):
         self.fuse_aggregation = False
         self.aggregation_scale = 1.0
 
+    def _radial_on_side(self, emb, side):
+        with torch.cuda.stream(side):
+            w = self.tp.weight_nn(emb)
+            ready = torch.cuda.Event()
+            ready.record(side)
+        emb.record_stream(side)
+        return w, ready
+
     def forward(self, data: DataKey.Type) -> DataKey.Type:
         emb = data[DataKey.EDGE_EMBEDDING]
-        w = None
+        w = ready = None
         if self.fuse_aggregation and ops.MLP_SIDE_STREAM and self.tp.weight_nn is not None and emb.is_cuda:
-            # the radial network beside linear_1 (and, in backward, beside the next convolution backward)
+            # The radial network runs on the side stream beside linear_1 (and, in backward, beside the
+            # next convolution backward).  It depends on the edge embedding only, so the layer that
+            # follows this one on the same embedding tensor (learnt from the previous pass) has its
+            # weights computed right behind ours, while this layer's convolution runs.
             main, side = torch.cuda.current_stream(emb.device), ops.side_stream(emb.device)
-            side.wait_stream(main)
-            with torch.cuda.stream(side):
-                w = self.tp.weight_nn(emb)
-            emb.record_stream(side)
+            key = (id(emb), emb._version, torch.is_grad_enabled())
+            pre = _PREFETCHED.pop(self, None)
+            if pre is not None and pre[0] == key and pre[1] is emb:
+                _, _, w, ready = pre
+            else:
+                side.wait_stream(main)
+                w, ready = self._radial_on_side(emb, side)
+            _note_radial_chain(self, key)
+            nxt = _NEXT_ON_EMBEDDING.get(self)
+            nxt = nxt() if nxt is not None else None
+            if ops.MLP_PREFETCH and nxt is not None and nxt is not self and nxt.fuse_aggregation and nxt.tp.weight_nn is not None:
+                _PREFETCHED[nxt] = (key, emb) + nxt._radial_on_side(emb, side)
         x = self.linear_1(data[DataKey.NODE_FEATURES])
         if w is not None:
-            main.wait_stream(side)
+            main.wait_event(ready)
             w.record_stream(main)
         ordering = ops.edge_ordering(data[DataKey.EDGE_INDEX], x.shape[0])
         if self.fuse_aggregation:

@@ -557,6 +557,8 @@ def _gemm_workspace(n_floats: int) -> torch.Tensor:
 # which slows down by more than is gained - config 3: 3.71 -> 3.85 ms.)  TFC_MLP_SIDE_STREAM=0 keeps
 # everything on one stream.
 MLP_SIDE_STREAM = _os_environ.get("TFC_MLP_SIDE_STREAM", "1") != "0"
+# the next layer's radial network right behind the current one's (TFC_MLP_PREFETCH=0: each layer its own)
+MLP_PREFETCH = _os_environ.get("TFC_MLP_PREFETCH", "1") != "0"
 _SIDE_STREAMS: "dict[int, torch.cuda.Stream]" = {}
 
 
