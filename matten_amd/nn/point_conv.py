@@ -110,10 +110,18 @@ class PointConvMessage(ModuleIrreps, torch.nn.Module):
                 side.wait_stream(main)
                 w, ready = self._radial_on_side(emb, side)
             _note_radial_chain(self, key)
-            nxt = _NEXT_ON_EMBEDDING.get(self)
-            nxt = nxt() if nxt is not None else None
-            if ops.MLP_PREFETCH and nxt is not None and nxt is not self and nxt.fuse_aggregation and nxt.tp.weight_nn is not None:
-                _PREFETCHED[nxt] = (key, emb) + nxt._radial_on_side(emb, side)
+            # (ops.MLP_PREFETCH_DEPTH layers ahead; one without gradients, where the weights of a layer
+            # can be freed before the next ones are computed)
+            cur = self
+            for _ in range(ops.MLP_PREFETCH_DEPTH if torch.is_grad_enabled() else 1):
+                nxt = _NEXT_ON_EMBEDDING.get(cur)
+                nxt = nxt() if nxt is not None else None
+                if not ops.MLP_PREFETCH or nxt is None or nxt is self or not nxt.fuse_aggregation or nxt.tp.weight_nn is None:
+                    break
+                have = _PREFETCHED.get(nxt)
+                if have is None or have[0] != key or have[1] is not emb:
+                    _PREFETCHED[nxt] = (key, emb) + nxt._radial_on_side(emb, side)
+                cur = nxt
         x = self.linear_1(data[DataKey.NODE_FEATURES])
         if w is not None:
             main.wait_event(ready)
