@@ -93,6 +93,20 @@ class PointConvMessage(ModuleIrreps, torch.nn.Module):
         emb.record_stream(side)
         return w, ready
 
+    def _prefetch_next(self, key, emb, side):
+        # (ops.MLP_PREFETCH_DEPTH layers ahead; one without gradients, where the weights of a layer
+        # can be freed before the next ones are computed)
+        cur = self
+        for _ in range(ops.MLP_PREFETCH_DEPTH if torch.is_grad_enabled() else 1):
+            nxt = _NEXT_ON_EMBEDDING.get(cur)
+            nxt = nxt() if nxt is not None else None
+            if not ops.MLP_PREFETCH or nxt is None or nxt is self or not nxt.fuse_aggregation or nxt.tp.weight_nn is None:
+                break
+            have = _PREFETCHED.get(nxt)
+            if have is None or have[0] != key or have[1] is not emb:
+                _PREFETCHED[nxt] = (key, emb) + nxt._radial_on_side(emb, side)
+            cur = nxt
+
     def forward(self, data: DataKey.Type) -> DataKey.Type:
         emb = data[DataKey.EDGE_EMBEDDING]
         w = ready = None
@@ -110,18 +124,8 @@ class PointConvMessage(ModuleIrreps, torch.nn.Module):
                 side.wait_stream(main)
                 w, ready = self._radial_on_side(emb, side)
             _note_radial_chain(self, key)
-            # (ops.MLP_PREFETCH_DEPTH layers ahead; one without gradients, where the weights of a layer
-            # can be freed before the next ones are computed)
-            cur = self
-            for _ in range(ops.MLP_PREFETCH_DEPTH if torch.is_grad_enabled() else 1):
-                nxt = _NEXT_ON_EMBEDDING.get(cur)
-                nxt = nxt() if nxt is not None else None
-                if not ops.MLP_PREFETCH or nxt is None or nxt is self or not nxt.fuse_aggregation or nxt.tp.weight_nn is None:
-                    break
-                have = _PREFETCHED.get(nxt)
-                if have is None or have[0] != key or have[1] is not emb:
-                    _PREFETCHED[nxt] = (key, emb) + nxt._radial_on_side(emb, side)
-                cur = nxt
+            if not ops.MLP_PREFETCH_AFTER_CONV:
+                self._prefetch_next(key, emb, side)
         x = self.linear_1(data[DataKey.NODE_FEATURES])
         if w is not None:
             main.wait_event(ready)
@@ -132,6 +136,10 @@ class PointConvMessage(ModuleIrreps, torch.nn.Module):
                 x, data[DataKey.EDGE_ATTRS], emb, ordering=ordering, scale=self.aggregation_scale, weight=w
             )
             data.pop(DataKey.EDGE_MESSAGE, None)
+            if w is not None and ops.MLP_PREFETCH_AFTER_CONV:
+                # behind this layer's convolution: beside the small products that follow it
+                side.wait_stream(main)
+                self._prefetch_next(key, emb, side)
         else:
             w = self.tp.weight_nn(data[DataKey.EDGE_EMBEDDING]) if self.tp.weight_nn is not None else None
             if w is None:

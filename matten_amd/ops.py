@@ -561,6 +561,7 @@ MLP_SIDE_STREAM = _os_environ.get("TFC_MLP_SIDE_STREAM", "1") != "0"
 MLP_PREFETCH = _os_environ.get("TFC_MLP_PREFETCH", "1") != "0"
 # layers computed ahead.  1: more would not shorten the step (config 3: 3.44 ms either way) and moves the
 # radial networks' backward, through autograd's ordering, onto the convolution backward of earlier layers
+MLP_PREFETCH_AFTER_CONV = _os_environ.get("TFC_MLP_PREFETCH_AFTER_CONV", "0") != "0"
 MLP_PREFETCH_DEPTH = int(_os_environ.get("TFC_MLP_PREFETCH_DEPTH", "1"))
 _SIDE_STREAMS: "dict[int, torch.cuda.Stream]" = {}
 
