@@ -11,6 +11,7 @@ algorithm for exactly the pieces the reference calls:
   * o3.Linear, o3.FullyConnectedTensorProduct (eigenn/nn/point_conv.py:56-61,130-135,160-162)
   * nn.FullyConnectedNet + normalize2mom    (eigenn/nn/utils.py:247-252)
   * nn.Gate (Activation + ElementwiseTensorProduct) (eigenn/nn/utils.py:134-140)
+  * nn.NormActivation                        (eigenn/nn/utils.py:142-150)
 
 Parity unpinned (see oracle/__init__.py): pinned only by first-principles tests.
 Everything is plain PyTorch on CPU so that autograd provides the backward.
