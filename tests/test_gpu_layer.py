@@ -35,3 +35,37 @@ def test_cpu_tensors_are_refused(device):
 
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         Linear("4x0e", "4x0e")(torch.randn(3, 4))
+
+
+def test_stream_modes_give_identical_bits(device, monkeypatch):
+    """The side stream and the prefetch of the next layer's radial network only reorder independent work:
+    energies, forces and every parameter gradient are bit-identical with one stream, with the side stream
+    but no prefetch, with the prefetch (default), and with the prefetch queued behind the convolution - and
+    over repeated passes (the prefetch only engages from the second pass on)."""
+    from matten_amd import ops
+    from tests.parity import CONFIGS, Stack, make_batch, run_stack
+
+    cfg = CONFIGS["minimal"]
+    torch.manual_seed(35)
+    batch = make_batch(cfg)
+    model = Stack("hip", cfg)
+    state = {k: v.clone() for k, v in model.state_dict().items()}
+
+    def run(side, prefetch, after):
+        monkeypatch.setattr(ops, "MLP_SIDE_STREAM", side)
+        monkeypatch.setattr(ops, "MLP_PREFETCH", prefetch)
+        monkeypatch.setattr(ops, "MLP_PREFETCH_AFTER_CONV", after)
+        m = Stack("hip", cfg)
+        m.load_state_dict(state)
+        outs = [run_stack(m, batch, str(device), torch.float32) for _ in range(3)]
+        torch.cuda.synchronize()
+        for o in outs[1:]:
+            for k, v in outs[0].items():
+                assert (v is None and o[k] is None) or torch.equal(v, o[k]), k
+        return outs[0]
+
+    ref = run(False, False, False)
+    for mode in [(True, False, False), (True, True, False), (True, True, True)]:
+        got = run(*mode)
+        for k, v in ref.items():
+            assert (v is None and got[k] is None) or torch.equal(v, got[k]), (mode, k)
