@@ -2,13 +2,17 @@
 """bench.py - conv edges/sec, forward + backward, of the tensor-field convolution hot path.
 
     python bench.py --gpus N --steps K --warmup W [--workload c3|c4|c5]
-    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+    (N > 1 either under the launcher, python -m torch.distributed.run --nnodes=1 --nproc-per-node N ...
+    bench.py --gpus N ..., or directly: the parent then starts that launcher itself as a child process,
+    before anything touches a GPU, and exits with its status)
 
 One step = one pass of the hot path over one synthetic batch, inputs already resident in HBM:
 edge encoders (spherical harmonics + Bessel) -> 3 x PointConvMessagePassing -> energy, then the
 backward that yields every parameter gradient AND the forces (-dE/dpos), then (N > 1) one flat
 gradient all-reduce over RCCL.  Work is data parallel over whole graphs, per-GPU batch fixed
-(weak scaling), no edge sharding.  value = sum over ranks of (edges x conv layers) / max-rank time.
+(weak scaling), no edge sharding.  value = sum over ranks of (edges x conv layers) / max-rank time, i.e.
+edges pushed through a convolution layer (forward + backward) per second: "edge-layers/s"; the rate of
+batch edges through the whole 3-layer model is value / 3 (`model_edges_per_s`).
 
 Also on the JSON line: `roofline` for the dominant kernel (tfc_conv_bwd_kernel; HBM-bound;
 algorithmic bytes per SURVEY.md §8d, duration from HIP events recorded by the library on the
@@ -76,21 +80,24 @@ def mfma_roofline(kern, flops, tags):
             "flops_per_step": flops, "ms_per_step": ms, "kernels": [t for t in tags if t in kern]}
 
 
-def pmc_traffic(workload):
-    """HBM bytes per conv-backward launch from the committed rocprofv3 PMC passes of this same
+def pmc_traffic(workload, kernel="tfc_conv_bwd_kernel"):
+    """(HBM bytes per launch of `kernel`, file) from the committed rocprofv3 PMC passes of this same
     command (FETCH_SIZE and WRITE_SIZE in separate runs, corrected with the calibration launches of
-    tools/pmc_calibrate.py as MI355X_MICROARCH.md prescribes; tools/pmc_traffic.py).  None when no
-    such profile is committed for the workload."""
+    tools/pmc_calibrate.py as MI355X_MICROARCH.md prescribes; tools/pmc_traffic.py).  Hardware counters
+    cannot be read from inside the process, so this is the one figure of the line that is not measured
+    live: (None, None) when no such profile is committed for the workload."""
     import glob
 
     hits = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", f"pmc_traffic_{workload}.json")))
     if not hits:
-        return None
+        return None, None
     try:
         with open(hits[-1]) as f:
-            return float(json.load(f)["kernels"]["tfc_conv_bwd_kernel"]["avg_bytes_per_launch"])
+            ks = json.load(f)["kernels"]
+        name = next(k for k in ks if k.startswith(kernel))
+        return float(ks[name]["avg_bytes_per_launch"]), os.path.relpath(hits[-1], ROOT)
     except Exception:
-        return None
+        return None, None
 
 
 def build_batch(wl, rank, device):
@@ -99,10 +106,9 @@ def build_batch(wl, rank, device):
     from matten_amd import keys as K
 
     batch, _ = synthetic_batch(wl["n"], wl["a"], wl["graphs"], seed0=1000 + rank * wl["graphs"], r_cut=R_CUT)
-    deg = batch[K.EDGE_INDEX].shape[1] / batch[K.POSITIONS].shape[0]
     batch["species_index"] = species_index(batch[K.ATOMIC_NUMBERS])
     batch = {k: v.to(device) for k, v in batch.items()}
-    return batch, deg
+    return batch
 
 
 def cpu_baseline(wl, avg_neigh, state, n_graphs_sample, threads):
@@ -136,7 +142,7 @@ def cpu_baseline(wl, avg_neigh, state, n_graphs_sample, threads):
     med = sorted(times)[len(times) // 2]
     return {
         "value": n_edges * wl["layers"] / med,
-        "unit": "edges/s",
+        "unit": "edge-layers/s",
         "cores": threads,
         "kind": "port",
         "sample": f"{n_graphs_sample} of the {wl['graphs']} graphs of the batch ({n_edges} edges), median of {len(times)} fwd+bwd steps, fp32",
@@ -153,6 +159,9 @@ def main():
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse N ranks on one GPU)")
     ap.add_argument("--overlap", type=int, default=0, help="1: launch the gradient all-reduce in slices from grad hooks during backward (not yet timed over RCCL, see tools/rehearse_dp.py)")
     ap.add_argument("--check", action="store_true", help="also verify a small case against the oracle before timing")
+    ap.add_argument("--dist-single", action="store_true",
+                    help="with --gpus 1: still initialise the process group (world size 1) and run the gradient all-reduce and the "
+                         "MAX/SUM reductions through it, so that the RCCL path executes on a one-GPU box")
     args = ap.parse_args()
 
     if os.environ.get("TFC_BENCH_WATCHDOG"):  # debugging aid: dump every thread's stack and exit after N seconds
@@ -162,14 +171,37 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # Called directly: start one rank per GPU under torch's launcher as a CHILD process.  Nothing in this
+        # process has touched a GPU yet (device_count() does not initialise the runtime on this image), and it
+        # never will: it only waits and hands the child's exit status on.
+        import socket
+        import subprocess
+
+        have = torch.cuda.device_count()
+        if have < args.gpus:
+            raise SystemExit(f"bench.py: --gpus {args.gpus} needs {args.gpus} devices, this machine shows {have}")
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        raise SystemExit(subprocess.call(cmd))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}")
     dist = None
-    if world > 1:
+    if world > 1 or args.dist_single:
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if "MASTER_PORT" not in os.environ:
+            import socket
+
+            with socket.socket() as sk:
+                sk.bind(("127.0.0.1", 0))
+                os.environ["MASTER_PORT"] = str(sk.getsockname()[1])
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         if args.backend == "nccl":
             torch.cuda.set_device(local_rank)
             dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
@@ -191,9 +223,14 @@ def main():
         r = run_layer_parity("smoke", device=str(device))
         assert r["ok"], f"parity check failed: {r['worst']}"
 
-    batch, deg = build_batch(wl, rank, device)
+    batch = build_batch(wl, rank, device)
     n_nodes, n_edges = int(batch[K.POSITIONS].shape[0]), int(batch[K.EDGE_INDEX].shape[1])
-    avg_neigh = 28.0 if wl["a"] > 2.2 else 56.0  # dataset constant (same on every rank)
+    # average_num_neighbors: a dataset constant in the reference (mean over the atoms of the training set,
+    # eigenn/dataset/matbench.py:148-162); here the mean over the atoms of all ranks' batches, same on every rank
+    cnt = torch.tensor([float(n_edges), float(n_nodes)], dtype=torch.float64, device=device)
+    if dist is not None:
+        dist.all_reduce(cnt, op=dist.ReduceOp.SUM)
+    avg_neigh = float(cnt[0].item() / cnt[1].item())
     torch.manual_seed(35)
     model = ConvStack(H, wl["emb"], wl["lmax"], wl["irreps"], wl["layers"], 64, 2, R_CUT, avg_neigh)
     state = {k: v.clone() for k, v in model.state_dict().items()}
@@ -204,7 +241,8 @@ def main():
     # launched from grad hooks so that they overlap with the rest of backward
     from matten_amd.dp import FlatGradBucket
 
-    bucket = FlatGradBucket(params, overlap=bool(args.overlap), bucket_bytes=int(os.environ.get("TFC_BUCKET_BYTES", 8 << 20)))
+    bucket = FlatGradBucket(params, overlap=bool(args.overlap), bucket_bytes=int(os.environ.get("TFC_BUCKET_BYTES", 8 << 20)),
+                            force=args.dist_single)
 
     pos0 = batch[K.POSITIONS]
     _SYNC_BEFORE_AR = bool(os.environ.get("TFC_SYNC_BEFORE_AR"))  # rehearsal aid
@@ -283,15 +321,20 @@ def main():
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": ach / HBM_PEAK_GBS,
-                "traffic": pmc_traffic(args.workload),
                 "bytes_per_launch": bytes_per_launch,
                 "avg_launch_ms": tot / c,
             }
+            # `frac` prices the ALGORITHMIC bytes (every operand as if read from HBM once); `traffic` is what the
+            # counters saw reach HBM (gathered rows are served from L2 / Infinity Cache), `traffic_frac` its rate
+            roof["traffic"], roof["traffic_source"] = pmc_traffic(args.workload)
+            roof["traffic_frac"] = roof["traffic"] / avg_s / 1e9 / HBM_PEAK_GBS if roof["traffic"] else None
             if "tfc_conv_fwd_kernel" in prof:
                 c2, tot2 = prof["tfc_conv_fwd_kernel"]
                 ach2 = (fb / n_layers) / (tot2 / c2 * 1e-3) / 1e9
+                tr2, _ = pmc_traffic(args.workload, "tfc_conv_fwd_kernel")
                 roof["fwd_kernel"] = {"achieved": ach2, "frac": ach2 / HBM_PEAK_GBS, "avg_launch_ms": tot2 / c2,
-                                      "bytes_per_launch": fb / n_layers}
+                                      "bytes_per_launch": fb / n_layers, "traffic": tr2,
+                                      "traffic_frac": tr2 / (tot2 / c2 * 1e-3) / 1e9 / HBM_PEAK_GBS if tr2 else None}
                 # the north star's figure: the convolution forward + backward together
                 both = (fb + bb) / n_layers / ((tot / c + tot2 / c2) * 1e-3) / 1e9
                 roof["fwd_plus_bwd"] = {"achieved": both, "frac": both / HBM_PEAK_GBS}
@@ -307,11 +350,12 @@ def main():
             try:
                 cpu = cpu_baseline(wl, avg_neigh, state, sample, threads)
             except Exception as ex:  # the baseline is a report, never a reason to lose the GPU number
-                cpu = {"value": None, "unit": "edges/s", "cores": threads, "kind": "port", "sample": f"failed: {ex}"}
+                cpu = {"value": None, "unit": "edge-layers/s", "cores": threads, "kind": "port", "sample": f"failed: {ex}"}
         out = {
             "metric": "conv edges/sec fwd+bwd",
             "value": value,
-            "unit": "edges/s",
+            "unit": "edge-layers/s",
+            "model_edges_per_s": value / wl["layers"],
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
@@ -326,8 +370,9 @@ def main():
                 "nodes_per_gpu": n_nodes,
                 "edges_per_gpu": n_edges,
                 "conv_layers": wl["layers"],
+                "avg_num_neighbors": avg_neigh,
                 "step": "edge encoders + 3 conv layers forward, backward to all parameters and positions (forces)"
-                + (f", gradient all-reduce ({args.backend}) in {len(bucket.bounds)} slices" + (" overlapped with backward" if args.overlap else " after backward") if world > 1 else ""),
+                + (f", gradient all-reduce ({args.backend}) in {len(bucket.bounds)} slices" + (" overlapped with backward" if args.overlap else " after backward") if dist is not None else ""),
                 "parallelism": f"dp{world}",
                 "layer_shapes": shapes,
             },
@@ -336,6 +381,10 @@ def main():
             "cpu_baseline": cpu,
             "kernels": kern,
         }
+        rl = kern.get("mlp_fused_fwd", {}).get("launches_per_step")
+        out["radial_mlp_launches_per_step"] = rl
+        if rl is not None and abs(rl - n_layers) > 1e-9:  # one radial network per layer and step, prefetched or not
+            print(f"bench.py: WARNING {rl} radial-network launches per step for {n_layers} layers", file=sys.stderr)
         print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()

@@ -34,7 +34,7 @@ class FlatGradBucket:
     gradients: last layer first) and cut into slices of at least `bucket_bytes`; a slice's
     all-reduce is launched (async, on the backend's own stream) from a post-accumulate hook as
     soon as its last gradient has been written, in slice order on every rank, while the earlier
-    layers are still in backward.  `all_reduce_mean()` launches whatever is left (slices whose
+    layers are still in backward (`overlap=True`; opt-in until it has been timed over RCCL).  `all_reduce_mean()` launches whatever is left (slices whose
     parameters got no gradient), waits and divides.  With `overlap=False` there are no hooks and
     the buffer is one slice: a single all-reduce after backward.
 
@@ -42,7 +42,8 @@ class FlatGradBucket:
     kept large: the default cap of 8 MB gives 3 slices at config 3 (22 MB of gradients), of which
     only the last, smallest one (the first layer's) is exposed after backward ends."""
 
-    def __init__(self, params: Iterable[torch.nn.Parameter], bucket_bytes: int = 8 << 20, overlap: bool = True, group=None):
+    def __init__(self, params: Iterable[torch.nn.Parameter], bucket_bytes: int = 8 << 20, overlap: bool = False, group=None,
+                 force: bool = False):
         self.params = [p for p in params if p.requires_grad]
         if not self.params:
             raise ValueError("no trainable parameters")
@@ -53,6 +54,8 @@ class FlatGradBucket:
         self.flat = torch.zeros(sum(p.numel() for p in self.params), dtype=dt, device=dev)
         self.group = group
         self.overlap = overlap
+        self.force = force  # run the collectives even in a group of one rank (exercises the RCCL path on one GPU)
+        self._views = {}  # id(param) -> (offset, numel): where its gradient lives in `flat`
         self.bounds: List[Tuple[int, int]] = []  # [begin, end) of each slice in `flat`
         self._slice_of = {}
         self._n_in_slice: List[int] = []
@@ -60,6 +63,7 @@ class FlatGradBucket:
         item = self.flat.element_size()
         for p in reversed(self.params):
             p.grad = self.flat[off : off + p.numel()].view_as(p)
+            self._views[id(p)] = (off, p.numel())
             self._slice_of[id(p)] = len(self.bounds)
             off += p.numel()
             count += 1
@@ -79,7 +83,11 @@ class FlatGradBucket:
     def _active(self) -> bool:
         import torch.distributed as dist
 
-        return dist.is_available() and dist.is_initialized() and dist.get_world_size(self.group) > 1
+        return dist.is_available() and dist.is_initialized() and (self.force or dist.get_world_size(self.group) > 1)
+
+    def _aliased(self, p) -> bool:
+        off, n = self._views[id(p)]
+        return p.grad is not None and p.grad.data_ptr() == self.flat.data_ptr() + off * self.flat.element_size() and p.grad.numel() == n
 
     def _launch(self, i: int):
         import torch.distributed as dist
@@ -99,8 +107,13 @@ class FlatGradBucket:
 
     # ---- per step
     def zero(self):
-        """Start of a step: clears the gradients and re-arms the slices."""
+        """Start of a step: clears the gradients and re-arms the slices.  Gradients that no longer alias the
+        buffer (optimizer.zero_grad() sets them to None by default) are pointed back into it."""
         self.flat.zero_()
+        for p in self.params:
+            if not self._aliased(p):
+                off, n = self._views[id(p)]
+                p.grad = self.flat[off : off + n].view_as(p)
         self._pending = list(self._n_in_slice)
         self._works = [None] * len(self.bounds)
         self._next = 0
@@ -113,6 +126,12 @@ class FlatGradBucket:
             return
         import torch.distributed as dist
 
+        for p in self.params:
+            if not self._aliased(p):
+                # e.g. optimizer.zero_grad(set_to_none=True) after zero(): backward then wrote to a fresh tensor
+                # and the buffer holds stale zeros; reducing it would silently desynchronise the ranks
+                raise RuntimeError("FlatGradBucket: a parameter's .grad no longer aliases the flat buffer; call bucket.zero() "
+                                   "at the start of every step instead of optimizer.zero_grad()")
         for i in range(len(self.bounds)):
             if self._works[i] is None:
                 self._launch(i)

@@ -16,6 +16,7 @@ from __future__ import annotations
 
 from typing import Dict, Optional
 
+import threading
 import weakref
 
 import torch
@@ -44,20 +45,46 @@ def compile_mode(mode: str):
 
 
 # Prefetch state of the side-stream radial networks, kept outside the modules (they stay picklable
-# and deep-copyable): which layer used the same embedding tensor right after which (learnt from the
-# previous pass), and the weights a layer's predecessor has already computed for it.
-_LAST_RADIAL = [None, None]  # (layer weakref, embedding key) of the most recent side-stream radial network
-_NEXT_ON_EMBEDDING = weakref.WeakKeyDictionary()  # layer -> weakref of its successor
-_PREFETCHED = weakref.WeakKeyDictionary()  # layer -> (key, embedding, weights, event)
+# and deep-copyable) and per host thread (two threads driving two models never see each other's
+# state): which layer ran right after which IN THE SAME PASS (learnt from the previous pass), and
+# the weights a layer's predecessor has already computed for it.
+#
+# A pass is the run of layers that see one edge-embedding tensor; a layer that shows up a second
+# time starts a new pass, so the last layer of a model is never linked to the first one (the weights
+# it would prefetch belong to a step whose parameters are not known yet).  Prefetched weights are
+# keyed on the embedding tensor (identity, address, version), the grad mode AND the versions of the
+# successor's radial-network parameters, so an optimiser step or load_state_dict between two passes
+# on the same embedding tensor can never be answered with weights of the old parameters.
+class _RadialChain(threading.local):
+    def __init__(self):
+        self.pass_key = None
+        self.pass_layers = []  # weakrefs of the layers of the current pass, in order
+        self.next_of = weakref.WeakKeyDictionary()  # layer -> weakref of its successor
+        self.prefetched = weakref.WeakKeyDictionary()  # layer -> (key, embedding, weights, event)
 
 
-def _note_radial_chain(layer, key):
-    prev, prev_key = _LAST_RADIAL
-    if prev is not None and prev_key == key:
-        p = prev()
-        if p is not None and p is not layer:
-            _NEXT_ON_EMBEDDING[p] = weakref.ref(layer)
-    _LAST_RADIAL[0], _LAST_RADIAL[1] = weakref.ref(layer), key
+_CHAIN = _RadialChain()
+
+
+def _radial_key(layer, emb):
+    """Everything the radial network's output depends on besides the values of `emb`."""
+    return (id(emb), emb.data_ptr(), emb._version, torch.is_grad_enabled(),
+            tuple((p.data_ptr(), p._version) for p in layer.tp.weight_nn.parameters()))
+
+
+def _note_radial_chain(layer, emb_key):
+    st = _CHAIN
+    seen = [r() for r in st.pass_layers]
+    if st.pass_key != emb_key or any(l is layer for l in seen):
+        st.pass_key, st.pass_layers = emb_key, []  # a new pass: no link from the previous pass's last layer
+    elif seen and seen[-1] is not None:
+        st.next_of[seen[-1]] = weakref.ref(layer)
+    st.pass_layers.append(weakref.ref(layer))
+
+
+def reset_prefetch_state():
+    """Forget the learnt layer order and drop prefetched weights (tests; also safe at any time)."""
+    _CHAIN.__init__()
 
 
 class PointConvMessage(ModuleIrreps, torch.nn.Module):
@@ -93,18 +120,21 @@ class PointConvMessage(ModuleIrreps, torch.nn.Module):
         emb.record_stream(side)
         return w, ready
 
-    def _prefetch_next(self, key, emb, side):
+    def _prefetch_next(self, emb, side):
         # (ops.MLP_PREFETCH_DEPTH layers ahead; one without gradients, where the weights of a layer
         # can be freed before the next ones are computed)
         cur = self
+        done = [r() for r in _CHAIN.pass_layers]  # never prefetch for a layer that already ran in this pass
         for _ in range(ops.MLP_PREFETCH_DEPTH if torch.is_grad_enabled() else 1):
-            nxt = _NEXT_ON_EMBEDDING.get(cur)
+            nxt = _CHAIN.next_of.get(cur)
             nxt = nxt() if nxt is not None else None
-            if not ops.MLP_PREFETCH or nxt is None or nxt is self or not nxt.fuse_aggregation or nxt.tp.weight_nn is None:
+            if (not ops.MLP_PREFETCH or nxt is None or any(nxt is l for l in done) or not nxt.fuse_aggregation
+                    or nxt.tp.weight_nn is None):
                 break
-            have = _PREFETCHED.get(nxt)
+            key = _radial_key(nxt, emb)
+            have = _CHAIN.prefetched.get(nxt)
             if have is None or have[0] != key or have[1] is not emb:
-                _PREFETCHED[nxt] = (key, emb) + nxt._radial_on_side(emb, side)
+                _CHAIN.prefetched[nxt] = (key, emb) + nxt._radial_on_side(emb, side)
             cur = nxt
 
     def forward(self, data: DataKey.Type) -> DataKey.Type:
@@ -116,16 +146,16 @@ class PointConvMessage(ModuleIrreps, torch.nn.Module):
             # follows this one on the same embedding tensor (learnt from the previous pass) has its
             # weights computed right behind ours, while this layer's convolution runs.
             main, side = torch.cuda.current_stream(emb.device), ops.side_stream(emb.device)
-            key = (id(emb), emb._version, torch.is_grad_enabled())
-            pre = _PREFETCHED.pop(self, None)
+            key = _radial_key(self, emb)
+            pre = _CHAIN.prefetched.pop(self, None)
             if pre is not None and pre[0] == key and pre[1] is emb:
                 _, _, w, ready = pre
             else:
                 side.wait_stream(main)
                 w, ready = self._radial_on_side(emb, side)
-            _note_radial_chain(self, key)
+            _note_radial_chain(self, key[:4])
             if not ops.MLP_PREFETCH_AFTER_CONV:
-                self._prefetch_next(key, emb, side)
+                self._prefetch_next(emb, side)
         x = self.linear_1(data[DataKey.NODE_FEATURES])
         if w is not None:
             main.wait_event(ready)
@@ -139,7 +169,7 @@ class PointConvMessage(ModuleIrreps, torch.nn.Module):
             if w is not None and ops.MLP_PREFETCH_AFTER_CONV:
                 # behind this layer's convolution: beside the small products that follow it
                 side.wait_stream(main)
-                self._prefetch_next(key, emb, side)
+                self._prefetch_next(emb, side)
         else:
             w = self.tp.weight_nn(data[DataKey.EDGE_EMBEDDING]) if self.tp.weight_nn is not None else None
             if w is None:

@@ -74,6 +74,7 @@ class EdgeOrdering:
             raise ValueError(f"edge_index must have shape [2, E], got {tuple(edge_index.shape)}")
         if not edge_index.is_cuda:
             raise RuntimeError("matten_amd: edge_index must live on a ROCm device (no CPU fallback exists)")
+        check_edge_orderings()  # the deferred verdict on earlier orderings (see below)
         ei = edge_index.to(torch.int64).contiguous()
         self.edge_index = ei
         self.n_nodes = int(n_nodes)
@@ -100,6 +101,18 @@ class EdgeOrdering:
         self.by_src = build(0, 1, 1)  # centre = sender,   nbr = receiver
         self._edge_rows = None
         self._m_cache = {}
+        self._host_status = None
+        if VALIDATE_EDGES == "sync":
+            self.validate()
+        elif VALIDATE_EDGES == "deferred" and E:
+            # the flag travels to pinned host memory behind the build; whoever builds the next ordering (or calls
+            # check_edge_orderings()) reads it without stalling the queue - an index error surfaces one batch
+            # late, like any asynchronous device-side error
+            self._host_status = torch.empty(2, dtype=torch.int32, pin_memory=True)
+            self._host_status.copy_(self.status, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(dev))
+            _PENDING_STATUS.append((ev, self._host_status, E, N))
 
     @classmethod
     def from_neighbor_list(cls, edge_index: torch.Tensor, n_nodes: int, row_ptr: torch.Tensor) -> "EdgeOrdering":
@@ -167,6 +180,30 @@ class EdgeOrdering:
 
 
 _ORDER_CACHE: "dict[int, tuple]" = {}
+# TFC_VALIDATE_EDGES: "deferred" (default; see EdgeOrdering.__init__), "sync" (raise at once: one host
+# synchronisation per new edge_index tensor) or "off".  The reference raises IndexError from its gather when
+# an edge names a node outside [0, N); here such edges are dropped from the groupings and flagged.
+VALIDATE_EDGES = _os_environ.get("TFC_VALIDATE_EDGES", "deferred")
+_PENDING_STATUS: "list[tuple]" = []
+
+
+def check_edge_orderings(wait: bool = False):
+    """Raise IndexError if an edge ordering built earlier saw node ids outside [0, n_nodes).  Only flags that
+    have already arrived on the host are looked at unless `wait`."""
+    keep = []
+    bad = None
+    for ev, flags, e, n in _PENDING_STATUS:
+        if wait:
+            ev.synchronize()
+        if ev.query():
+            if int(flags.max()) != 0:
+                bad = (e, n)
+        else:
+            keep.append((ev, flags, e, n))
+    _PENDING_STATUS[:] = keep
+    if bad is not None:
+        raise IndexError(f"edge_index ({bad[0]} edges) contains node ids outside [0, {bad[1]}); those edges were dropped "
+                         "from the convolution of an EARLIER batch, whose results are invalid")
 
 
 def edge_ordering(edge_index: torch.Tensor, n_nodes: int) -> EdgeOrdering:
@@ -407,13 +444,16 @@ class _EdgeGeometryFn(torch.autograd.Function):
         vec, length = ctx.saved_tensors
         E = vec.shape[0]
         dvec = torch.empty_like(vec)
+        # (contiguous copies are bound to names: a temporary would be freed, and its block possibly reused by the
+        # next argument's copy, before the kernel that reads it has been queued)
+        dsh = _f32(dsh, "dsh") if dsh is not None else None
+        dvec_in = _f32(dvec_in, "dvec") if dvec_in is not None else None
+        dlen = _f32(dlen, "dlen") if dlen is not None else None
         if E:
             _lib.check(
                 _lib.lib().tfc_edge_encode_bwd(
                     _ptr(vec), _ptr(length), E, max(ctx.lmax, 0), 1 if ctx.sh_normalize else 0, None, 0, 1.0, 6.0,
-                    _ptr(_f32(dsh, "dsh")) if dsh is not None else None, None,
-                    _ptr(_f32(dvec_in, "dvec")) if dvec_in is not None else None,
-                    _ptr(_f32(dlen, "dlen")) if dlen is not None else None, _ptr(dvec), None, _stream(),
+                    _ptr(dsh), None, _ptr(dvec_in), _ptr(dlen), _ptr(dvec), None, _stream(),
                 )
             )
         dcell = None
@@ -455,11 +495,12 @@ class _ShFn(torch.autograd.Function):
     def backward(ctx, dsh):
         (vec,) = ctx.saved_tensors
         dvec = torch.empty_like(vec)
+        dsh = _f32(dsh, "dsh")
         if vec.shape[0]:
             _lib.check(
                 _lib.lib().tfc_edge_encode_bwd(
                     _ptr(vec), None, vec.shape[0], ctx.lmax, 1 if ctx.normalize else 0, None, 0, 1.0, 6.0,
-                    _ptr(_f32(dsh, "dsh")), None, None, None, _ptr(dvec), None, _stream(),
+                    _ptr(dsh), None, None, None, _ptr(dvec), None, _stream(),
                 )
             )
         return dvec, None, None
@@ -499,9 +540,10 @@ class _RadialFn(torch.autograd.Function):
             return dvec, None, torch.zeros_like(bw) if ctx.needs_input_grad[2] else None, None, None
         nb = int(_lib.lib().tfc_edge_bwd_blocks(E))
         part = torch.empty(nb, B, dtype=torch.float32, device=vec.device) if ctx.needs_input_grad[2] else None
+        demb = _f32(demb, "demb")
         _lib.check(
             _lib.lib().tfc_edge_encode_bwd(
-                _ptr(vec), _ptr(length), E, 0, 1, _ptr(bw), B, ctx.r_max, ctx.p, None, _ptr(_f32(demb, "demb")), None,
+                _ptr(vec), _ptr(length), E, 0, 1, _ptr(bw), B, ctx.r_max, ctx.p, None, _ptr(demb), None,
                 None, _ptr(dvec), _ptr(part), _stream(),
             )
         )

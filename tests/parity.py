@@ -38,6 +38,11 @@ CONFIGS = {
                               graphs=3, hint=False),
     # activation_type="norm" (NormActivation instead of Gate, eigenn/nn/utils.py:142-150)
     "norm_act": dict(emb=8, lmax=2, irreps="8x0o+8x0e+4x1o+4x1e+2x2o+2x2e", layers=2, hidden=16, nh=2, n=2, a=2.6, graphs=2, act="norm"),
+    # config 5's cell at full size (12^3 = 1728 atoms, a = 2.1: ~97 k edges, ~56 neighbours per atom, ONE graph:
+    # the single-cell branch of with_edge_vectors) through one conv layer of config 3's first-layer shape
+    # (D_in 64, W 192, D_mid 576): the fp64 oracle's per-edge tensors still fit in host memory at this size
+    "c5_layer0": dict(emb=64, lmax=2, irreps="64x0o+64x0e+64x1o+64x1e+64x2o+64x2e", layers=1, hidden=64, nh=2, n=12, a=2.1, graphs=1,
+                      low_rank=True),
     "c4": dict(emb=128, lmax=3, irreps="128x0o+128x0e+128x1o+128x1e+128x2o+128x2e+128x3o+128x3e", layers=2, hidden=64, nh=2, n=2, a=2.6, graphs=1),
 }
 R_CUT = 5.0

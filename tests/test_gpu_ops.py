@@ -46,10 +46,19 @@ def test_csr_build_bit_exact(device, n_nodes, n_edges):
 def test_csr_flags_bad_index(device):
     from matten_amd import ops
 
+    ops.check_edge_orderings(wait=True)  # nothing pending from earlier tests
     ei = torch.tensor([[0, 1, 5], [1, 0, 1]], device=device)
     o = ops.EdgeOrdering(ei, 3)
     with pytest.raises(IndexError):
         o.validate()
+    # the deferred report: the flag reaches the host behind the build, and the next ordering that is built (or
+    # an explicit check) raises - the reference's gather would have raised at once (eigenn/nn/point_conv.py:82)
+    torch.cuda.synchronize()
+    with pytest.raises(IndexError, match="outside"):
+        ops.edge_ordering(torch.tensor([[0, 1], [1, 0]], device=device), 2)
+    ops.check_edge_orderings(wait=True)  # reported once, then forgotten
+    good = ops.edge_ordering(torch.tensor([[0, 1], [1, 0]], device=device), 2)
+    good.validate()
 
 
 # --------------------------------------------------------------------------------------- gemm
@@ -293,6 +302,12 @@ def test_gate_vs_oracle(device, scalars, acts_s, gates, acts_g, gated):
         ("96x0e+70x1o+130x2e", "0e+1o+2e", "96x0e+70x1o+130x2e+70x1e", 9, 100),
         ("16x0e+16x1o+8x2e+4x3o", "0e+1o+2e+3o", "16x0o+16x0e+16x1o+16x1e+8x2o+8x2e+4x3o+4x3e", 12, 200),
         ("8x0e+8x3o+8x3e", "0e+1o+2e+3o", "8x0e+8x1o+8x2e+8x3o+8x3e", 6, 1),
+        # receivers with more than 64 / more than 128 incoming edges (the forward kernel's chunked edge loop, its
+        # tail chunk and the remainder of its unrolled groups), channel counts that are not multiples of 64
+        ("96x0e+70x1o+130x2e", "0e+1o+2e", "96x0e+70x1o+130x2e+70x1e", 5, 3000),
+        ("40x0e+24x1o+24x1e+10x2e", "0e+1o+2e", "40x0o+40x0e+24x1o+24x1e+10x2o+10x2e", 3, 451),
+        ("20x0e+12x1o+6x2e+3x3o", "0e+1o+2e+3o", "20x0o+20x0e+12x1o+12x1e+6x2o+6x2e+3x3o+3x3e", 4, 333),
+        ("64x0e+64x1o", "0e+1o+2e", "64x0e+64x1o+64x1e+64x2e", 2, 130),
     ],
 )
 @pytest.mark.parametrize("need_dy", [True, False])

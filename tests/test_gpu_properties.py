@@ -1,7 +1,8 @@
 """-m gpu: size-independent properties of the hot path at BASELINE.json's FULL sizes (config 3:
-2048 atoms / ~59 k edges; config 4: 6912 atoms / ~200 k edges), where the CPU oracle would take
-minutes: invariances and covariances the domain guarantees, linearity, batch independence,
-determinism, and bit-exact structure of the integer work."""
+2048 atoms / ~59 k edges; config 4: 6912 atoms / ~200 k edges, lmax 3, 128 channels; config 5: one
+1728-atom cell / ~97 k edges), each through the whole 3-layer energy model, where the CPU oracle
+would take minutes: invariances and covariances the domain guarantees, linearity, batch
+independence, determinism, and bit-exact structure of the integer work."""
 import math
 
 import numpy as np
@@ -12,25 +13,31 @@ pytestmark = pytest.mark.gpu
 
 C3 = dict(n=4, a=2.5, graphs=32, emb=64, sh="0e + 1o + 2e", irreps="64x0o+64x0e+64x1o+64x1e+64x2o+64x2e")
 C4 = dict(n=6, a=2.5, graphs=32, emb=128, sh="0e + 1o + 2e + 3o", irreps="128x0o+128x0e+128x1o+128x1e+128x2o+128x2e+128x3o+128x3e")
+C5 = dict(n=12, a=2.1, graphs=1, emb=64, sh="0e + 1o + 2e", irreps="64x0o+64x0e+64x1o+64x1e+64x2o+64x2e", avg=56.0)
+FULL = {"c3": C3, "c4": C4, "c5": C5}
 
 
 def _hparams(cfg, layers=3):
     return dict(
         species_embedding_dim=cfg["emb"], irreps_edge_sh=cfg["sh"], num_radial_basis=8, radial_basis_r_cut=5.0, num_layers=layers,
-        invariant_layers=2, invariant_neurons=64, average_num_neighbors=28.0, conv_layer_irreps=cfg["irreps"],
+        invariant_layers=2, invariant_neurons=64, average_num_neighbors=cfg.get("avg", 28.0), conv_layer_irreps=cfg["irreps"],
         nonlinearity_type="gate", use_sc=True, resnet=True, conv_to_output_hidden_irreps_out="16x0e", reduce="sum",
     )
 
 
-@pytest.fixture(scope="module")
-def c3(device):
+@pytest.fixture(scope="module", params=["c3", "c4", "c5"])
+def c3(request, device):
+    """(model, batch, graphs, atoms per graph) of one full-size configuration; the fixture keeps its first name."""
     from matten_amd import model_factory
     from matten_amd.data.crystal import synthetic_batch
 
-    batch, graphs = synthetic_batch(C3["n"], C3["a"], C3["graphs"], seed0=1000, r_cut=5.0)
+    cfg = FULL[request.param]
+    batch, graphs = synthetic_batch(cfg["n"], cfg["a"], cfg["graphs"], seed0=1000, r_cut=5.0)
     torch.manual_seed(35)
-    model = model_factory.create_energy_model(_hparams(C3), {"allowed_species": (1, 6, 8, 14)}).to(device)
-    return model, {k: v.to(device) for k, v in batch.items()}, graphs
+    model = model_factory.create_energy_model(_hparams(cfg), {"allowed_species": (1, 6, 8, 14)}).to(device)
+    yield model, {k: v.to(device) for k, v in batch.items()}, graphs
+    del model
+    torch.cuda.empty_cache()
 
 
 def _energy_forces(model, batch, grads=False):
@@ -58,7 +65,7 @@ def test_full_size_rotation_and_inversion(c3, device):
     along; cell shifts are integers and stay)."""
     model, batch, _ = c3
     e0, f0, _ = _energy_forces(model, batch)
-    assert batch["pos"].shape[0] == 2048 and e0.shape == (32,)
+    assert batch["pos"].shape[0] in (2048, 6912, 1728) and e0.shape[0] in (32, 1)
     for Rm in (_rotation(5), -torch.eye(3, dtype=torch.float64), -_rotation(6)):
         Rf = Rm.to(device=device, dtype=torch.float32)
         b = dict(batch)
@@ -86,8 +93,9 @@ def test_full_size_edge_and_graph_permutation(c3, device):
     b2 = {k: v.to(device) for k, v in collate([graphs[i] for i in order]).items()}
     e2, f2, _ = _energy_forces(model, b2)
     assert _rel(e2.flip(0), e0) < 1e-5
-    n_at = 64
-    assert _rel(f2.reshape(32, n_at, 3).flip(0).reshape(-1, 3), f0) < 1e-5
+    n_g = len(graphs)
+    n_at = batch["pos"].shape[0] // n_g
+    assert _rel(f2.reshape(n_g, n_at, 3).flip(0).reshape(-1, 3), f0) < 1e-5
 
 
 def test_full_size_batch_independence_and_translation(c3, device):
@@ -96,15 +104,17 @@ def test_full_size_batch_independence_and_translation(c3, device):
 
     model, batch, graphs = c3
     e0, f0, _ = _energy_forces(model, batch)
-    for g in (0, 17, 31):
+    n_g = len(graphs)
+    n_at = batch["pos"].shape[0] // n_g
+    for g in sorted({0, 17 % n_g, n_g - 1}):
         single = {k: v.to(device) for k, v in collate([graphs[g]]).items()}
         e1, f1, _ = _energy_forces(model, single)
-        assert _rel(e1, e0[g : g + 1]) < 1e-5 and _rel(f1, f0[64 * g : 64 * (g + 1)]) < 1e-5
+        assert _rel(e1, e0[g : g + 1]) < 1e-5 and _rel(f1, f0[n_at * g : n_at * (g + 1)]) < 1e-5
     b = dict(batch)
     b["pos"] = batch["pos"] + torch.tensor([0.37, -1.2, 2.9], device=device)
     e2, f2, _ = _energy_forces(model, b)
     assert _rel(e2, e0) < 1e-5 and _rel(f2, f0) < 1e-5
-    assert f0.reshape(32, 64, 3).sum(1).abs().max().item() < 1e-4 * f0.abs().max().item() * 64  # forces sum to zero per crystal
+    assert f0.reshape(n_g, n_at, 3).sum(1).abs().max().item() < 1e-4 * f0.abs().max().item() * n_at  # forces sum to zero per crystal
 
 
 def test_full_size_determinism(c3):
