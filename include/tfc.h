@@ -75,6 +75,18 @@ int tfc_csr_build(const int64_t* key, const int64_t* other, int64_t n_edges, int
                   int32_t* row_ptr, int32_t* eid, int32_t* nbr, int32_t* status, void* workspace,
                   tfc_stream_t stream);
 
+/* tfc_csr_build for callers that cannot allocate device memory (code under HIP graph capture, tight
+ * serving loops, harnesses that forbid hipMalloc).  No counterpart in the reference.  Same arguments and
+ * results as tfc_csr_build minus `workspace`: the cursors and the unsorted edge queue live in a static
+ * device array of TFC_CSR_NOALLOC_MAX_INTS int32 (16 MiB per GPU the library runs on, held until the
+ * process ends), so n_nodes + n_edges + 2 must not exceed that (TFC_EUNSUPPORTED otherwise).  The call
+ * allocates and frees nothing; on its first use on a device it looks up that device's address of the
+ * array.  Every call on a GPU shares that GPU's array: calls that overlap on one GPU (two streams, two
+ * threads) race - order them.  Nothing in the array has to be cleared between calls. */
+#define TFC_CSR_NOALLOC_MAX_INTS (1 << 22)
+int tfc_csr_build_noalloc(const int64_t* key, const int64_t* other, int64_t n_edges, int64_t n_nodes,
+                          int32_t* row_ptr, int32_t* eid, int32_t* nbr, int32_t* status, tfc_stream_t stream);
+
 /* The unfused route, for callers that materialise per-edge messages and sum them afterwards
  * (scatter_add, eigenn/nn/utils.py:351-357, and its backward, a row gather):
  *   tfc_segment_sum: out[n] = sum_{k in rows(n)} src[eid[k]]   src [E,d] -> out [N,d], no atomics

@@ -114,6 +114,7 @@ SIGNATURES = {
     "tfc_real_cg": (C.c_int, [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double)]),
     "tfc_csr_workspace_bytes": (_I64, [_I64, _I64]),
     "tfc_csr_build": (C.c_int, [_P, _P, _I64, _I64, _P, _P, _P, _P, _P, _P]),
+    "tfc_csr_build_noalloc": (C.c_int, [_P, _P, _I64, _I64, _P, _P, _P, _P, _P]),
     "tfc_segment_sum": (C.c_int, [_P, _P, _P, _I64, _I32, _P, _P]),
     "tfc_gather_rows": (C.c_int, [_P, _P, _I64, _I64, _I32, _P, _P]),
     "tfc_nl_count": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _I64, _I64, C.c_double, _P, _P]),

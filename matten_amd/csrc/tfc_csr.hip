@@ -4,6 +4,12 @@
 #include "tfc_common.h"
 
 #include <algorithm>
+#include <mutex>
+
+// Scratch of tfc_csr_build_noalloc (cursors + the unsorted edge queue), one copy per GPU the library
+// runs on, held until the process ends.  In host code this name is only a stand-in for the symbol:
+// the device address is asked for once per device (csr_static_scratch) and used from then on.
+static __device__ __align__(256) int32_t tfc_csr_scratch[TFC_CSR_NOALLOC_MAX_INTS];
 
 __global__ __launch_bounds__(256) void tfc_csr_count_kernel(const int64_t* __restrict__ key,
                                                             const int64_t* __restrict__ other, long n_edges,
@@ -143,16 +149,10 @@ extern "C" int64_t tfc_csr_workspace_bytes(int64_t n_nodes, int64_t n_edges) {
     return (n_nodes + n_edges + 2) * (int64_t)sizeof(int32_t);
 }
 
-extern "C" int tfc_csr_build(const int64_t* key, const int64_t* other, int64_t n_edges, int64_t n_nodes,
-                             int32_t* row_ptr, int32_t* eid, int32_t* nbr, int32_t* status, void* workspace,
-                             tfc_stream_t stream_) {
-    hipStream_t stream = (hipStream_t)stream_;
-    TFC_REQUIRE(n_edges >= 0 && n_nodes >= 0, TFC_EINVAL, "tfc_csr_build: negative size");
-    TFC_REQUIRE(n_edges < (1LL << 31) - 1 && n_nodes < (1LL << 31) - 1, TFC_EUNSUPPORTED,
-                "tfc_csr_build: more than 2^31 nodes or edges");
-    TFC_REQUIRE(row_ptr && status && workspace, TFC_EINVAL, "tfc_csr_build: null output");
-    TFC_REQUIRE(n_edges == 0 || (key && other && eid && nbr), TFC_EINVAL, "tfc_csr_build: null tensor");
-    int* cursor = (int*)workspace;
+static int csr_build_impl(const int64_t* key, const int64_t* other, int64_t n_edges, int64_t n_nodes,
+                          int32_t* row_ptr, int32_t* eid, int32_t* nbr, int32_t* status, int* workspace,
+                          hipStream_t stream) {
+    int* cursor = workspace;
     int* tmp = cursor + n_nodes + 1;
     TFC_HIP(hipMemsetAsync(row_ptr, 0, (size_t)(n_nodes + 1) * sizeof(int32_t), stream));
     TFC_HIP(hipMemsetAsync(status, 0, sizeof(int32_t), stream));
@@ -168,4 +168,54 @@ extern "C" int tfc_csr_build(const int64_t* key, const int64_t* other, int64_t n
     tfc_csr_sort_kernel<<<ng, 256, 0, stream>>>(row_ptr, tmp, other, (long)n_nodes, eid, nbr);
     TFC_LAUNCH_CHECK("tfc_csr_sort_kernel");
     return TFC_OK;
+}
+
+extern "C" int tfc_csr_build(const int64_t* key, const int64_t* other, int64_t n_edges, int64_t n_nodes,
+                             int32_t* row_ptr, int32_t* eid, int32_t* nbr, int32_t* status, void* workspace,
+                             tfc_stream_t stream_) {
+    TFC_REQUIRE(n_edges >= 0 && n_nodes >= 0, TFC_EINVAL, "tfc_csr_build: negative size");
+    TFC_REQUIRE(n_edges < (1LL << 31) - 1 && n_nodes < (1LL << 31) - 1, TFC_EUNSUPPORTED,
+                "tfc_csr_build: more than 2^31 nodes or edges");
+    TFC_REQUIRE(row_ptr && status && workspace, TFC_EINVAL, "tfc_csr_build: null output");
+    TFC_REQUIRE(n_edges == 0 || (key && other && eid && nbr), TFC_EINVAL, "tfc_csr_build: null tensor");
+    return csr_build_impl(key, other, n_edges, n_nodes, row_ptr, eid, nbr, status, (int*)workspace,
+                          (hipStream_t)stream_);
+}
+
+// Device address of this GPU's copy of tfc_csr_scratch: looked up on the first call on a device (with that
+// device current), kept per device afterwards.
+static int csr_static_scratch(int32_t** out) {
+    constexpr int kMaxDevices = 64;
+    static std::mutex mu;
+    static int32_t* ptrs[kMaxDevices] = {};
+    int dev = -1;
+    TFC_HIP(hipGetDevice(&dev));
+    TFC_REQUIRE(dev >= 0 && dev < kMaxDevices, TFC_EUNSUPPORTED, "tfc_csr_build_noalloc: device index %d", dev);
+    std::lock_guard<std::mutex> lock(mu);
+    if (!ptrs[dev]) {
+        void* p = nullptr;
+        TFC_HIP(hipGetSymbolAddress(&p, HIP_SYMBOL(tfc_csr_scratch)));
+        TFC_REQUIRE(p, TFC_ELAUNCH, "tfc_csr_build_noalloc: no device address for the scratch array");
+        ptrs[dev] = (int32_t*)p;
+    }
+    *out = ptrs[dev];
+    return TFC_OK;
+}
+
+extern "C" int tfc_csr_build_noalloc(const int64_t* key, const int64_t* other, int64_t n_edges, int64_t n_nodes,
+                                     int32_t* row_ptr, int32_t* eid, int32_t* nbr, int32_t* status,
+                                     tfc_stream_t stream_) {
+    TFC_REQUIRE(n_edges >= 0 && n_nodes >= 0, TFC_EINVAL, "tfc_csr_build_noalloc: negative size");
+    TFC_REQUIRE(n_nodes + n_edges + 2 <= (int64_t)TFC_CSR_NOALLOC_MAX_INTS, TFC_EUNSUPPORTED,
+                "tfc_csr_build_noalloc: %lld nodes + %lld edges + 2 exceed the static scratch of %d entries "
+                "(use tfc_csr_build with a caller workspace)",
+                (long long)n_nodes, (long long)n_edges, (int)TFC_CSR_NOALLOC_MAX_INTS);
+    TFC_REQUIRE(row_ptr && status, TFC_EINVAL, "tfc_csr_build_noalloc: null output");
+    TFC_REQUIRE(n_edges == 0 || (key && other && eid && nbr), TFC_EINVAL, "tfc_csr_build_noalloc: null tensor");
+    int32_t* scratch = nullptr;
+    const int rc = csr_static_scratch(&scratch);
+    if (rc) return rc;
+    // nothing in the scratch has to start at zero: the scan seeds every cursor, the fill writes every queue
+    // slot the sort reads
+    return csr_build_impl(key, other, n_edges, n_nodes, row_ptr, eid, nbr, status, scratch, (hipStream_t)stream_);
 }
