@@ -159,6 +159,10 @@ def main():
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse N ranks on one GPU)")
     ap.add_argument("--overlap", type=int, default=0, help="1: launch the gradient all-reduce in slices from grad hooks during backward (not yet timed over RCCL, see tools/rehearse_dp.py)")
     ap.add_argument("--check", action="store_true", help="also verify a small case against the oracle before timing")
+    ap.add_argument("--graph", type=int, default=1,
+                    help="1 (default): the step (forward + backward into the flat gradient buffer) is captured once into a HIP graph "
+                         "and every timed step is one replay of it (the gradient all-reduce stays outside the graph); 0: every step is "
+                         "issued launch by launch from Python")
     ap.add_argument("--dist-single", action="store_true",
                     help="with --gpus 1: still initialise the process group (world size 1) and run the gradient all-reduce and the "
                          "MAX/SUM reductions through it, so that the RCCL path executes on a one-GPU box")
@@ -247,17 +251,40 @@ def main():
     pos0 = batch[K.POSITIONS]
     _SYNC_BEFORE_AR = bool(os.environ.get("TFC_SYNC_BEFORE_AR"))  # rehearsal aid
 
-    def step():
+    def compute():
         bucket.zero()
         b = dict(batch)
         pos = pos0.detach().requires_grad_(True)
         b[K.POSITIONS] = pos
         _, energy, _ = model(b, wl["graphs"])
         energy.sum().backward()
+        return pos.grad  # = -forces
+
+    def eager_step():
+        g = compute()
         if _SYNC_BEFORE_AR:
             torch.cuda.synchronize()
         bucket.all_reduce_mean()
-        return pos.grad  # = -forces
+        return g
+
+    step = eager_step
+    mode = "eager"
+    if args.graph and not args.overlap:
+        # The batch shape is fixed, so the ~170 launches of a step are captured once and replayed: same kernels,
+        # same arithmetic, same bits (tests/test_gpu_graph.py), no per-launch host work.
+        from matten_amd.graphs import GraphedStep
+
+        try:
+            replay = GraphedStep(compute)
+        except Exception as ex:  # capture refused: keep the launch-by-launch step
+            print(f"bench.py: HIP-graph capture failed ({ex}); timing the eager step", file=sys.stderr)
+        else:
+            mode = "hip_graph_replay"
+
+            def step():
+                g = replay()
+                bucket.all_reduce_mean()
+                return g
 
     def sync():
         if dist is not None:
@@ -269,7 +296,8 @@ def main():
     sync()
     L = _lib.lib()
     L.tfc_profile_reset()
-    L.tfc_profile_enable(0 if os.environ.get("TFC_BENCH_NOPROF") else 2)  # HIP events around the conv kernels only, on their launch stream
+    # HIP events around the conv kernels only, on their launch stream (eager steps; see below for graph replays)
+    L.tfc_profile_enable(0 if os.environ.get("TFC_BENCH_NOPROF") or mode != "eager" else 2)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
@@ -277,12 +305,23 @@ def main():
     elapsed = time.perf_counter() - t0
     L.tfc_profile_enable(0)
     prof = _lib.profile_report()
+    if mode != "eager":
+        # HIP events cannot be recorded between the nodes of a replayed graph, so the conv-kernel durations come from
+        # K eager steps of the same work, right behind the timed replays (same process, same buffers); the rocprofv3
+        # kernel trace of this command (profiles/) times the kernels inside the replays themselves
+        L.tfc_profile_reset()
+        L.tfc_profile_enable(2)
+        for _ in range(args.steps):
+            eager_step()
+        sync()
+        L.tfc_profile_enable(0)
+        prof = _lib.profile_report()
     # per-kernel breakdown of a step (informational; outside the timed region)
     L.tfc_profile_reset()
     L.tfc_profile_enable(1)
     n_break = 3
     for _ in range(n_break):
-        step()
+        eager_step()
     sync()
     L.tfc_profile_enable(0)
     prof_all = _lib.profile_report()
@@ -371,6 +410,7 @@ def main():
                 "edges_per_gpu": n_edges,
                 "conv_layers": wl["layers"],
                 "avg_num_neighbors": avg_neigh,
+                "launch": mode,
                 "step": "edge encoders + 3 conv layers forward, backward to all parameters and positions (forces)"
                 + (f", gradient all-reduce ({args.backend}) in {len(bucket.bounds)} slices" + (" overlapped with backward" if args.overlap else " after backward") if dist is not None else ""),
                 "parallelism": f"dp{world}",

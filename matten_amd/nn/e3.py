@@ -169,9 +169,15 @@ class FullyConnectedNet(torch.nn.Module):
         for i, (a, b) in enumerate(zip(self.hs, self.hs[1:])):
             setattr(self, f"layer{i}", _FcLayer(a, b))
 
-    def forward(self, x):
-        ws = [getattr(self, f"layer{i}").weight for i in range(len(self.hs) - 1)]
-        return ops.radial_mlp(x, ws, self.act_cst)
+    def _weights(self):
+        return [getattr(self, f"layer{i}").weight for i in range(len(self.hs) - 1)]
+
+    def forward(self, x, pre=None):
+        """`pre`: this network's activations for `x`, from precompute() (see ops.radial_mlp)."""
+        return ops.radial_mlp(x, self._weights(), self.act_cst, pre)
+
+    def precompute(self, x):
+        return ops.radial_mlp_precompute(x, self._weights(), self.act_cst)
 
     def extra_repr(self):
         return f"{self.hs} act={self.act}"

@@ -112,13 +112,28 @@ class PointConvMessage(ModuleIrreps, torch.nn.Module):
         self.fuse_aggregation = False
         self.aggregation_scale = 1.0
 
-    def _radial_on_side(self, emb, side):
+    def _radial_on_side(self, emb, side, pre=None):
+        """This layer's radial network under the side stream (so that its backward runs there too).  With
+        `pre` (activations a predecessor computed ahead of time, _prefetch_next) nothing is launched: the
+        call only records the autograd node, HERE in the forward order - had the prefetching layer recorded
+        it, autograd would run its backward after that earlier layer's convolution backward, at the very end
+        of the pass with nothing left to overlap it with."""
         with torch.cuda.stream(side):
-            w = self.tp.weight_nn(emb)
+            w = self.tp.weight_nn(emb, pre=pre)
+            ready = None
+            if pre is None:
+                ready = torch.cuda.Event()
+                ready.record(side)
+        emb.record_stream(side)
+        return w, ready
+
+    def _precompute_on_side(self, emb, side):
+        with torch.cuda.stream(side):
+            pre = self.tp.weight_nn.precompute(emb)
             ready = torch.cuda.Event()
             ready.record(side)
         emb.record_stream(side)
-        return w, ready
+        return pre, ready
 
     def _prefetch_next(self, emb, side):
         # (ops.MLP_PREFETCH_DEPTH layers ahead; one without gradients, where the weights of a layer
@@ -134,7 +149,10 @@ class PointConvMessage(ModuleIrreps, torch.nn.Module):
             key = _radial_key(nxt, emb)
             have = _CHAIN.prefetched.get(nxt)
             if have is None or have[0] != key or have[1] is not emb:
-                _CHAIN.prefetched[nxt] = (key, emb) + nxt._radial_on_side(emb, side)
+                if ops.MLP_PREFETCH_RECORD_EARLY:  # the autograd node recorded by the prefetching layer (round-1 order)
+                    _CHAIN.prefetched[nxt] = (key, emb) + nxt._radial_on_side(emb, side) + (True,)
+                else:
+                    _CHAIN.prefetched[nxt] = (key, emb) + nxt._precompute_on_side(emb, side) + (False,)
             cur = nxt
 
     def forward(self, data: DataKey.Type) -> DataKey.Type:
@@ -149,7 +167,8 @@ class PointConvMessage(ModuleIrreps, torch.nn.Module):
             key = _radial_key(self, emb)
             pre = _CHAIN.prefetched.pop(self, None)
             if pre is not None and pre[0] == key and pre[1] is emb:
-                _, _, w, ready = pre
+                ready = pre[3]
+                w = pre[2] if pre[4] else self._radial_on_side(emb, side, pre=pre[2])[0]
             else:
                 side.wait_stream(main)
                 w, ready = self._radial_on_side(emb, side)

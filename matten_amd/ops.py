@@ -187,6 +187,20 @@ VALIDATE_EDGES = _os_environ.get("TFC_VALIDATE_EDGES", "deferred")
 _PENDING_STATUS: "list[tuple]" = []
 
 
+def clear_caches():
+    """Drop everything the ops keep between calls (edge orderings and their M matrices, channel-contiguous
+    gradient copies, attribute factorizations, split-K workspaces).  They are rebuilt on demand; needed before a
+    HIP-graph capture (matten_amd.graphs), where freeing a cached tensor that an earlier eager step used on the
+    default stream would record an allocator event on that stream in the middle of the capture."""
+    torch.cuda.synchronize()
+    check_edge_orderings(wait=True)
+    _ORDER_CACHE.clear()
+    _TRANSPOSED.clear()
+    _ATTR_FACTORS.clear()
+    _ATTR_CLASSES.clear()
+    _GEMM_WS.clear()
+
+
 def check_edge_orderings(wait: bool = False):
     """Raise IndexError if an edge ordering built earlier saw node ids outside [0, n_nodes).  Only flags that
     have already arrived on the host are looked at unless `wait`."""
@@ -604,6 +618,12 @@ MLP_PREFETCH = _os_environ.get("TFC_MLP_PREFETCH", "1") != "0"
 # layers computed ahead.  1: more would not shorten the step (config 3: 3.44 ms either way) and moves the
 # radial networks' backward, through autograd's ordering, onto the convolution backward of earlier layers
 MLP_PREFETCH_AFTER_CONV = _os_environ.get("TFC_MLP_PREFETCH_AFTER_CONV", "0") != "0"
+# who records the autograd node of a prefetched radial network: the prefetching layer (1, default: its backward then
+# runs at the end of the pass, after the earlier layer's convolution backward) or the layer it belongs to (0: only
+# the launches are issued early; the backward runs beside the next convolution backward, as without prefetch).
+# Measured at config 3 (graph replay / eager): 3.39 / 3.53 ms against 3.50 / 3.69 - the convolution backward loses
+# more to the shared CUs than the exposed tail of two small networks costs
+MLP_PREFETCH_RECORD_EARLY = _os_environ.get("TFC_MLP_PREFETCH_RECORD_EARLY", "1") != "0"
 MLP_PREFETCH_DEPTH = int(_os_environ.get("TFC_MLP_PREFETCH_DEPTH", "1"))
 _SIDE_STREAMS: "dict[int, torch.cuda.Stream]" = {}
 
@@ -784,39 +804,52 @@ def linear(x, weight, spec: LinearSpec):
 # ------------------------------------------------------------------ radial FullyConnectedNet
 
 
+def _radial_mlp_run(x, ws, act_cst: float):
+    """The forward launches of the radial network: [x, h_1, ..., h_{L-1}, out] (no autograd)."""
+    E = x.shape[0]
+    hs = [x]
+    dims = [x.shape[1]] + [w.shape[1] for w in ws]
+    for i, w in enumerate(ws):
+        if w.shape[0] != dims[i]:
+            raise ValueError(f"radial mlp: layer {i} expects {w.shape[0]} inputs, got {dims[i]}")
+    nl = len(ws)
+    if 2 <= nl <= 6 and max(dims[:-1]) <= 64 and dims[-1] % 4 == 0 and ws[-1].data_ptr() % 16 == 0:
+        # whole network in one launch, hidden activations kept in LDS (tfc_radial_mlp_fwd)
+        outs = [torch.empty(E, d, dtype=torch.float32, device=x.device) for d in dims[1:]]
+        c_dims = (C.c_int32 * (nl + 1))(*dims)
+        c_w = (C.c_void_p * nl)(*[w.data_ptr() for w in ws])
+        c_h = (C.c_void_p * nl)(*([o.data_ptr() for o in outs[:-1]] + [None]))
+        _lib.check(_lib.lib().tfc_radial_mlp_fwd(_ptr(x), E, nl, c_dims, c_w, float(act_cst), c_h, _ptr(outs[-1]), _stream()))
+        hs += outs
+    else:
+        for i, w in enumerate(ws):
+            hin, hout = w.shape
+            out = torch.empty(E, hout, dtype=torch.float32, device=x.device)
+            last = i == nl - 1
+            _gemm(
+                E, hout, hin, _p(hs[-1]), _p(w), _p(out), a1_r=_lin(hin), a1_k=_lin(1), b_k=_lin(hout), b_j=_lin(1),
+                c_r=_lin(hout), c_j=_lin(1), alpha=1.0 / math.sqrt(hin),
+                epilogue=_lib.EPI_NONE if last else _lib.EPI_SSP, act_cst=act_cst, tag=b"gemm_mlp_fwd",
+            )
+            hs.append(out)
+    return hs
+
+
 class _RadialMlpFn(torch.autograd.Function):
-    """x -> act'(x W0/sqrt(h0)) -> ... -> h W_last/sqrt(h_last); act' = cst * ssp."""
+    """x -> act'(x W0/sqrt(h0)) -> ... -> h W_last/sqrt(h_last); act' = cst * ssp.
+
+    `pre`: the activations [h_1, ..., out] of exactly this input and these weights, computed earlier by
+    radial_mlp_precompute (e.g. on a side stream, ahead of time); the call then launches nothing and only
+    records the autograd node - at the place in the forward order, and under the current stream, its
+    backward should have."""
 
     @staticmethod
-    def forward(ctx, x, act_cst: float, *weights):
+    def forward(ctx, x, act_cst: float, pre, *weights):
         x = _f32(x, "edge_embedding")
         ws = [_f32(w, "mlp weight") for w in weights]
-        E = x.shape[0]
-        hs = [x]
-        dims = [x.shape[1]] + [w.shape[1] for w in ws]
-        for i, w in enumerate(ws):
-            if w.shape[0] != dims[i]:
-                raise ValueError(f"radial mlp: layer {i} expects {w.shape[0]} inputs, got {dims[i]}")
-        nl = len(ws)
-        if 2 <= nl <= 6 and max(dims[:-1]) <= 64 and dims[-1] % 4 == 0 and ws[-1].data_ptr() % 16 == 0:
-            # whole network in one launch, hidden activations kept in LDS (tfc_radial_mlp_fwd)
-            outs = [torch.empty(E, d, dtype=torch.float32, device=x.device) for d in dims[1:]]
-            c_dims = (C.c_int32 * (nl + 1))(*dims)
-            c_w = (C.c_void_p * nl)(*[w.data_ptr() for w in ws])
-            c_h = (C.c_void_p * nl)(*([o.data_ptr() for o in outs[:-1]] + [None]))
-            _lib.check(_lib.lib().tfc_radial_mlp_fwd(_ptr(x), E, nl, c_dims, c_w, float(act_cst), c_h, _ptr(outs[-1]), _stream()))
-            hs += outs
-        else:
-            for i, w in enumerate(ws):
-                hin, hout = w.shape
-                out = torch.empty(E, hout, dtype=torch.float32, device=x.device)
-                last = i == nl - 1
-                _gemm(
-                    E, hout, hin, _p(hs[-1]), _p(w), _p(out), a1_r=_lin(hin), a1_k=_lin(1), b_k=_lin(hout), b_j=_lin(1),
-                    c_r=_lin(hout), c_j=_lin(1), alpha=1.0 / math.sqrt(hin),
-                    epilogue=_lib.EPI_NONE if last else _lib.EPI_SSP, act_cst=act_cst, tag=b"gemm_mlp_fwd",
-                )
-                hs.append(out)
+        hs = [x] + list(pre) if pre is not None else _radial_mlp_run(x, ws, act_cst)
+        if len(hs) != len(ws) + 1 or hs[-1].shape != (x.shape[0], ws[-1].shape[1]):
+            raise ValueError("radial mlp: precomputed activations do not match the network")
         ctx.save_for_backward(*hs[:-1], *ws)
         ctx.n_layers, ctx.act_cst = len(ws), float(act_cst)
         return hs[-1]
@@ -829,7 +862,7 @@ class _RadialMlpFn(torch.autograd.Function):
         E = g.shape[0]
         dev = g.device
         dims = [hs[0].shape[1]] + [w.shape[1] for w in ws]
-        dws = [torch.empty_like(w) if ctx.needs_input_grad[2 + i] else None for i, w in enumerate(ws)]
+        dws = [torch.empty_like(w) if ctx.needs_input_grad[3 + i] else None for i, w in enumerate(ws)]
         dhid = [torch.empty(E, dims[i + 1], dtype=torch.float32, device=dev) for i in range(nl - 1)]
         dx = torch.empty(E, dims[0], dtype=torch.float32, device=dev) if ctx.needs_input_grad[0] else None
         L = _lib.lib()
@@ -841,11 +874,18 @@ class _RadialMlpFn(torch.autograd.Function):
             _ptr(hs[0]), E, nl, c_dims, vp(ws), ctx.act_cst, vp(hs[1:]), _ptr(g), vp(dhid), _ptr(dx), vp(dws),
             _ptr(wsp), wsp.numel() if wsp is not None else 0, _stream(),
         ))
-        return (dx, None, *dws)
+        return (dx, None, None, *dws)
 
 
-def radial_mlp(x, weights: Sequence[torch.Tensor], act_cst: float):
-    return _RadialMlpFn.apply(x, act_cst, *weights)
+def radial_mlp(x, weights: Sequence[torch.Tensor], act_cst: float, pre=None):
+    return _RadialMlpFn.apply(x, act_cst, pre, *weights)
+
+
+def radial_mlp_precompute(x, weights: Sequence[torch.Tensor], act_cst: float):
+    """The network's activations [h_1, ..., out] for `radial_mlp(..., pre=...)`: launches on the current stream,
+    records nothing for autograd."""
+    with torch.no_grad():
+        return _radial_mlp_run(_f32(x.detach(), "edge_embedding"), [_f32(w.detach(), "mlp weight") for w in weights], act_cst)[1:]
 
 
 # ------------------------------------------------------------------ FullyConnectedTensorProduct with scalar second input

@@ -51,10 +51,11 @@ def test_stream_modes_give_identical_bits(device, monkeypatch):
     model = Stack("hip", cfg)
     state = {k: v.clone() for k, v in model.state_dict().items()}
 
-    def run(side, prefetch, after):
+    def run(side, prefetch, after, early=True):
         monkeypatch.setattr(ops, "MLP_SIDE_STREAM", side)
         monkeypatch.setattr(ops, "MLP_PREFETCH", prefetch)
         monkeypatch.setattr(ops, "MLP_PREFETCH_AFTER_CONV", after)
+        monkeypatch.setattr(ops, "MLP_PREFETCH_RECORD_EARLY", early)
         m = Stack("hip", cfg)
         m.load_state_dict(state)
         outs = [run_stack(m, batch, str(device), torch.float32) for _ in range(3)]
@@ -65,7 +66,7 @@ def test_stream_modes_give_identical_bits(device, monkeypatch):
         return outs[0]
 
     ref = run(False, False, False)
-    for mode in [(True, False, False), (True, True, False), (True, True, True)]:
+    for mode in [(True, False, False), (True, True, False), (True, True, True), (True, True, False, False), (True, True, True, False)]:
         got = run(*mode)
         for k, v in ref.items():
             assert (v is None and got[k] is None) or torch.equal(v, got[k]), (mode, k)
@@ -115,9 +116,10 @@ def test_prefetch_never_serves_weights_of_old_parameters(device, monkeypatch):
     data0 = _encoded(ref_model, batch, str(device))
     emb = data0[K.EDGE_EMBEDDING]
 
-    def run(prefetch):
+    def run(prefetch, early=True):
         monkeypatch.setattr(ops, "MLP_SIDE_STREAM", True)
         monkeypatch.setattr(ops, "MLP_PREFETCH", prefetch)
+        monkeypatch.setattr(ops, "MLP_PREFETCH_RECORD_EARLY", early)
         point_conv.reset_prefetch_state()
         m = Stack("hip", cfg).to(device)
         m.load_state_dict(state)
@@ -143,12 +145,13 @@ def test_prefetch_never_serves_weights_of_old_parameters(device, monkeypatch):
         return outs, launches
 
     ref, n_ref = run(False)
-    got, n_got = run(True)
     assert n_ref == 5 * len(ref_model.convs)
-    assert n_got == n_ref, f"{n_got} radial-network launches with prefetch, {n_ref} without"
-    for a, b in zip(ref, got):
-        for x, y in zip(a, b):
-            assert torch.equal(x, y)
+    for early in (True, False):
+        got, n_got = run(True, early)
+        assert n_got == n_ref, f"{n_got} radial-network launches with prefetch, {n_ref} without"
+        for a, b in zip(ref, got):
+            for x, y in zip(a, b):
+                assert torch.equal(x, y)
     assert not torch.equal(ref[0][0], ref[1][0])  # the parameter update did change the result
 
 

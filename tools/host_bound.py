@@ -9,7 +9,7 @@ from matten_amd import keys as K
 from matten_amd.harness import ConvStack
 wl = bench.WORKLOADS[sys.argv[1] if len(sys.argv) > 1 else "c3"]
 dev = torch.device("cuda")
-batch, deg = bench.build_batch(wl, 0, dev)
+batch = bench.build_batch(wl, 0, dev)
 torch.manual_seed(35)
 model = ConvStack(H, wl["emb"], wl["lmax"], wl["irreps"], wl["layers"], 64, 2, 5.0, 28.0).to(dev)
 pos0 = batch[K.POSITIONS]
