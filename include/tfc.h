@@ -252,6 +252,19 @@ int tfc_edge_encode_bwd(const float* vec, const float* len, int64_t n_edges, int
                         const float* demb, const float* dvec_add, const float* dlen, float* dvec,
                         float* dbw_partial, tfc_stream_t stream);
 
+/* Second order of the encoders, for training on forces (a loss on F = -dE/dpos needs the derivative of the
+ * backward above; the reference gets it from autograd's double backward through e3nn / torch,
+ * eigenn/nn/_nequip.py:231-235).  With phi = sum dsh Y(vec) + sum demb emb(|vec|, bw) + dlen |vec|, the call
+ * above returns dvec = d phi / d vec and dbw = d phi / d bw.  Given cotangents gv [E,3] of dvec and gb [n_basis]
+ * of dbw (either may be null = zero) this returns the products autograd asks for:
+ *   g_vec [E,3], g_bw_partial [tfc_edge_bwd_blocks(E), n_basis] : Hessian of phi times (gv, gb)
+ *   g_dsh [E,(lmax+1)^2], g_demb [E,n_basis], g_dlen [E]        : Jacobians of Y, emb, |vec| times (gv, gb)
+ * (every output nullable).  Lengths are recomputed from vec.  One pass in dual-number arithmetic. */
+int tfc_edge_encode_bwd2(const float* vec, int64_t n_edges, int32_t lmax, int32_t sh_normalize, const float* bw,
+                         int32_t n_basis, float r_max, float p, const float* dsh, const float* demb,
+                         const float* dlen, const float* gv, const float* gb, float* g_vec, float* g_dsh,
+                         float* g_demb, float* g_dlen, float* g_bw_partial, tfc_stream_t stream);
+
 /* Scatter of the per-edge vector gradient to positions (and cells):
  *   dpos[n] = sum_{e: ei[1,e]=n} dvec[e] - sum_{e: ei[0,e]=n} dvec[e]
  * using the two orderings of tfc_csr_build (no atomics).  (rp_dst, eid_dst) group by ei[1],
@@ -439,6 +452,12 @@ int tfc_gate_fwd(const tfc_gate_seg* segs, int32_t n_segs, const float* x, int64
                  int32_t d_in, int32_t d_out, float* out, tfc_stream_t stream);
 int tfc_gate_bwd(const tfc_gate_seg* segs, int32_t n_segs, const float* x, const float* gout,
                  int64_t n_rows, int32_t d_in, int32_t d_out, float* dx, tfc_stream_t stream);
+
+/* Second order of the gate (double backward, see tfc_edge_encode_bwd2): tfc_gate_bwd returns dx = J(x)^T gout;
+ * for a cotangent v [n_rows, d_in] of dx this returns ggout = J(x) v [n_rows, d_out] and
+ * gx = d/dx (v^T J(x)^T gout) [n_rows, d_in] (either nullable). */
+int tfc_gate_bwd2(const tfc_gate_seg* segs, int32_t n_segs, const float* x, const float* gout, const float* v,
+                  int64_t n_rows, int32_t d_in, int32_t d_out, float* ggout, float* gx, tfc_stream_t stream);
 
 /* Norm activation: the `activation_type="norm"` branch of ActivationLayer (eigenn/nn/utils.py:142-150),
  * e3nn.nn.NormActivation(irreps_in, scalar_nonlinearity, normalize=True, epsilon=1e-8, bias=False):

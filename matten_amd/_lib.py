@@ -134,6 +134,8 @@ SIGNATURES = {
     "tfc_edge_encode_fwd": (C.c_int, [_P, _P, _P, _P, _P, _I64, _I64, _I64, _I32, _I32, _P, _I32, _F, _F, _P, _P, _P, _P, _P]),
     "tfc_edge_bwd_blocks": (_I64, [_I64]),
     "tfc_edge_encode_bwd": (C.c_int, [_P, _P, _I64, _I32, _I32, _P, _I32, _F, _F, _P, _P, _P, _P, _P, _P, _P]),
+    "tfc_edge_encode_bwd2": (C.c_int, [_P, _I64, _I32, _I32, _P, _I32, _F, _F, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "tfc_gate_bwd2": (C.c_int, [C.POINTER(GateSeg), _I32, _P, _P, _P, _I64, _I32, _I32, _P, _P, _P]),
     "tfc_edge_vec_bwd": (C.c_int, [_P, _P, _P, _P, _P, _I64, _P, _P]),
     "tfc_edge_cell_bwd": (C.c_int, [_P, _P, _P, _P, _I64, _P, _P]),
     "tfc_gemm": (C.c_int, [C.POINTER(GemmDesc), _P]),

@@ -268,6 +268,223 @@ __global__ __launch_bounds__(256) void tfc_edge_vec_bwd_kernel(const float* __re
     dpos[3 * n + c] = s - m;
 }
 
+
+// ------------------------------------------------------------------------------------------
+// Second order (double backward: training on forces F = -dE/dpos).  The backward above is the gradient of
+//     phi(v, b) = sum_q dsh[q] Y_q(v) + sum_n demb[n] emb_n(|v|, b_n) + dlen |v|
+// with respect to the edge vector v and the Bessel frequencies b.  What autograd needs from its backward is
+// the product of phi's Hessian with the incoming cotangents (gv for dvec, gb for dbw) and the Jacobians of
+// Y, emb and |v| applied to them.  Both are directional derivatives along (gv, gb), so the kernel evaluates
+// the forward and the backward formulas once more in dual-number arithmetic, a + eps b with eps^2 = 0: the
+// eps parts are exactly those products.
+struct Dual {
+    float a, b;
+};
+__device__ __forceinline__ Dual mk(float a, float b = 0.f) { return Dual{a, b}; }
+__device__ __forceinline__ Dual operator+(Dual x, Dual y) { return Dual{x.a + y.a, x.b + y.b}; }
+__device__ __forceinline__ Dual operator-(Dual x, Dual y) { return Dual{x.a - y.a, x.b - y.b}; }
+__device__ __forceinline__ Dual operator-(Dual x) { return Dual{-x.a, -x.b}; }
+__device__ __forceinline__ Dual operator*(Dual x, Dual y) { return Dual{x.a * y.a, fmaf(x.a, y.b, x.b * y.a)}; }
+__device__ __forceinline__ Dual operator*(float c, Dual y) { return Dual{c * y.a, c * y.b}; }
+__device__ __forceinline__ Dual operator*(Dual y, float c) { return Dual{c * y.a, c * y.b}; }
+__device__ __forceinline__ Dual operator+(Dual x, float c) { return Dual{x.a + c, x.b}; }
+__device__ __forceinline__ Dual operator+(float c, Dual x) { return Dual{x.a + c, x.b}; }
+__device__ __forceinline__ Dual operator-(float c, Dual x) { return Dual{c - x.a, -x.b}; }
+__device__ __forceinline__ Dual operator-(Dual x, float c) { return Dual{x.a - c, x.b}; }
+__device__ __forceinline__ Dual operator/(Dual x, Dual y) {
+    const float q = x.a / y.a;
+    return Dual{q, (x.b - q * y.b) / y.a};
+}
+__device__ __forceinline__ Dual operator/(Dual x, float c) { return Dual{x.a / c, x.b / c}; }
+__device__ __forceinline__ Dual& operator+=(Dual& x, Dual y) {
+    x.a += y.a;
+    x.b += y.b;
+    return x;
+}
+__device__ __forceinline__ Dual& operator-=(Dual& x, Dual y) {
+    x.a -= y.a;
+    x.b -= y.b;
+    return x;
+}
+__device__ __forceinline__ Dual dsqrt(Dual x) {
+    const float s = sqrtf(x.a);
+    return Dual{s, 0.5f * x.b / s};
+}
+__device__ __forceinline__ Dual dpow(Dual x, float p) {  // x^p, p constant
+    const float q = powf(x.a, p - 1.f);
+    return Dual{q * x.a, p * q * x.b};
+}
+__device__ __forceinline__ void dsincos(Dual x, Dual& sn, Dual& cs) {
+    float s, c;
+    sincosf(x.a, &s, &c);
+    sn = Dual{s, c * x.b};
+    cs = Dual{c, -s * x.b};
+}
+
+__device__ __forceinline__ void sh_eval_dual(int lmax, Dual x, Dual y, Dual z, Dual* __restrict__ o) {
+    o[0] = mk(1.f);
+    if (lmax >= 1) {
+        o[1] = SQ3 * x;
+        o[2] = SQ3 * y;
+        o[3] = SQ3 * z;
+    }
+    if (lmax >= 2) {
+        const Dual y2 = y * y, x2z2 = x * x + z * z;
+        const Dual s20 = SQ3 * (x * z), s24 = (0.5f * SQ3) * (z * z - x * x);
+        o[4] = SQ5 * s20;
+        o[5] = SQ15 * (x * y);
+        o[6] = SQ5 * (y2 - 0.5f * x2z2);
+        o[7] = SQ15 * (y * z);
+        o[8] = SQ5 * s24;
+        if (lmax >= 3) {
+            o[9] = A3 * (s20 * z + s24 * x);
+            o[10] = B3 * (s20 * y);
+            o[11] = C3 * ((4.f * y2 - x2z2) * x);
+            o[12] = (SQ7 * 0.5f) * (y * (2.f * y2 - 3.f * x2z2));
+            o[13] = C3 * (z * (4.f * y2 - x2z2));
+            o[14] = B3 * (s24 * y);
+            o[15] = A3 * (s24 * z - s20 * x);
+        }
+    }
+}
+
+// sh_grad in dual arithmetic (same polynomials, same coefficients d)
+__device__ __forceinline__ void sh_grad_dual(int lmax, Dual x, Dual y, Dual z, const float* __restrict__ d, Dual& gx,
+                                             Dual& gy, Dual& gz) {
+    gx = gy = gz = mk(0.f);
+    if (lmax >= 1) {
+        gx = gx + SQ3 * d[1];
+        gy = gy + SQ3 * d[2];
+        gz = gz + SQ3 * d[3];
+    }
+    if (lmax >= 2) {
+        gx += (SQ15 * d[4]) * z + (SQ15 * d[5]) * y - (SQ5 * d[6]) * x - (SQ15 * d[8]) * x;
+        gy += (SQ15 * d[5]) * x + (2.f * SQ5 * d[6]) * y + (SQ15 * d[7]) * z;
+        gz += (SQ15 * d[4]) * x - (SQ5 * d[6]) * z + (SQ15 * d[7]) * y + (SQ15 * d[8]) * z;
+    }
+    if (lmax >= 3) {
+        const float a = A3 * SQ3, b = B3 * SQ3;
+        const Dual x2 = x * x, y2 = y * y, z2 = z * z;
+        gx += (d[9] * a * 1.5f) * (z2 - x2);
+        gz += (d[9] * a * 3.f) * (x * z);
+        gx += (d[10] * b) * (y * z);
+        gy += (d[10] * b) * (x * z);
+        gz += (d[10] * b) * (x * y);
+        gx += (d[11] * C3) * (4.f * y2 - 3.f * x2 - z2);
+        gy += (d[11] * C3 * 8.f) * (x * y);
+        gz -= (d[11] * C3 * 2.f) * (x * z);
+        gx -= (d[12] * 3.f * SQ7) * (x * y);
+        gy += (d[12] * 0.5f * SQ7) * (6.f * y2 - 3.f * (x2 + z2));
+        gz -= (d[12] * 3.f * SQ7) * (y * z);
+        gx -= (d[13] * C3 * 2.f) * (x * z);
+        gy += (d[13] * C3 * 8.f) * (y * z);
+        gz += (d[13] * C3) * (4.f * y2 - x2 - 3.f * z2);
+        gx -= (d[14] * b) * (x * y);
+        gy += (d[14] * 0.5f * b) * (z2 - x2);
+        gz += (d[14] * b) * (y * z);
+        gx -= (d[15] * a * 3.f) * (x * z);
+        gz += (d[15] * a * 1.5f) * (z2 - x2);
+    }
+}
+
+__global__ __launch_bounds__(EDGE_BWD_BLOCK) void tfc_edge_bwd2_kernel(
+    const float* __restrict__ vec, long n_edges, int lmax, int sh_norm, const float* __restrict__ bw, int n_basis,
+    float r_max, float p, const float* __restrict__ dsh, const float* __restrict__ demb,
+    const float* __restrict__ dlen, const float* __restrict__ gv, const float* __restrict__ gb,
+    float* __restrict__ g_vec, float* __restrict__ g_dsh, float* __restrict__ g_demb, float* __restrict__ g_dlen,
+    float* __restrict__ g_bw_partial) {
+    __shared__ float red[4][8];
+    const int S = (lmax + 1) * (lmax + 1);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float gbw_acc[8];
+#pragma unroll
+    for (int n = 0; n < 8; ++n) gbw_acc[n] = 0.f;
+    const long stride = (long)gridDim.x * blockDim.x;
+    const long trips = (n_edges + stride - 1) / stride;
+    for (long it = 0; it < trips; ++it) {
+        const long e = it * stride + (long)blockIdx.x * blockDim.x + threadIdx.x;
+        if (e >= n_edges) continue;
+        const Dual vx = mk(vec[3 * e], gv ? gv[3 * e] : 0.f), vy = mk(vec[3 * e + 1], gv ? gv[3 * e + 1] : 0.f),
+                   vz = mk(vec[3 * e + 2], gv ? gv[3 * e + 2] : 0.f);
+        const Dual r2 = vx * vx + vy * vy + vz * vz;
+        const bool tiny = r2.a <= 1e-24f;  // F.normalize leaves a zero vector at zero: no dependence on it
+        const Dual r = tiny ? mk(1e-12f) : dsqrt(r2);
+        const Dual inv = mk(1.f) / r;
+        const Dual x = vx * inv, y = vy * inv, z = vz * inv;
+        Dual Gx = mk(0.f), Gy = mk(0.f), Gz = mk(0.f);
+        if (dsh) {
+            float d[16];
+            const float* dr = dsh + e * S;
+            for (int q = 0; q < S; ++q) d[q] = dr[q];
+            Dual o[16], px, py, pz;
+            if (sh_norm) {
+                sh_eval_dual(lmax, x, y, z, o);
+                sh_grad_dual(lmax, x, y, z, d, px, py, pz);
+                const Dual dot = px * x + py * y + pz * z;
+                if (!tiny) {
+                    Gx += (px - x * dot) * inv;
+                    Gy += (py - y * dot) * inv;
+                    Gz += (pz - z * dot) * inv;
+                }
+            } else {
+                sh_eval_dual(lmax, vx, vy, vz, o);
+                sh_grad_dual(lmax, vx, vy, vz, d, px, py, pz);
+                Gx += px;
+                Gy += py;
+                Gz += pz;
+            }
+            if (g_dsh)
+                for (int q = 0; q < S; ++q) g_dsh[e * S + q] = o[q].b;
+        }
+        if (demb) {
+            const Dual u = r / r_max;
+            const bool inside = r.a < r_max;
+            const Dual up1 = dpow(u, p - 1.f), up = up1 * u;
+            const float c1 = 0.5f * (p + 1.f) * (p + 2.f), c2 = p * (p + 2.f), c3 = 0.5f * p * (p + 1.f);
+            const Dual env = inside ? 1.f - c1 * up + c2 * (up * u) - c3 * (up * u * u) : mk(0.f);
+            const Dual denv = inside ? ((-c1 * p) * up1 + (c2 * (p + 1.f)) * up - (c3 * (p + 2.f)) * (up * u)) / r_max : mk(0.f);
+            const float pref = 2.f / r_max;
+            const float* de = demb + e * n_basis;
+            Dual dr = mk(0.f);
+            for (int n = 0; n < n_basis; ++n) {
+                const Dual b = mk(bw[n], gb ? gb[n] : 0.f);
+                Dual sn, cs;
+                dsincos(b * r / r_max, sn, cs);
+                const Dual sr = sn / r;
+                const float g = de[n];
+                if (g_demb) g_demb[e * n_basis + n] = (pref * (sr * env)).b;
+                dr += (g * pref) * (((b / r_max) * cs / r - sr / r) * env + sr * denv);
+                if (n < 8) gbw_acc[n] += ((g * pref / r_max) * (cs * env)).b;
+            }
+            Gx += dr * x;
+            Gy += dr * y;
+            Gz += dr * z;
+        }
+        if (dlen) {
+            const float g = dlen[e];
+            Gx += g * x;
+            Gy += g * y;
+            Gz += g * z;
+        }
+        if (g_dlen) g_dlen[e] = tiny ? 0.f : r.b;
+        if (g_vec) {
+            g_vec[3 * e] = Gx.b;
+            g_vec[3 * e + 1] = Gy.b;
+            g_vec[3 * e + 2] = Gz.b;
+        }
+    }
+    if (g_bw_partial) {
+        for (int n = 0; n < n_basis && n < 8; ++n) {
+            const float s = tfc_wave_sum(gbw_acc[n]);
+            if (lane == 0) red[wave][n] = s;
+        }
+        __syncthreads();
+        if (threadIdx.x < n_basis && threadIdx.x < 8)
+            g_bw_partial[(long)blockIdx.x * n_basis + threadIdx.x] =
+                red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+    }
+}
+
 }  // namespace
 
 extern "C" int tfc_edge_encode_fwd(const float* pos, const int64_t* edge_index, const float* shift,
@@ -369,5 +586,32 @@ extern "C" int tfc_edge_vec_bwd(const float* dvec, const int32_t* rp_src, const 
     tfc_edge_vec_bwd_kernel<<<(unsigned)((t + 255) / 256), 256, 0, stream>>>(dvec, rp_src, eid_src, rp_dst, eid_dst,
                                                                              (long)n_nodes, dpos);
     TFC_LAUNCH_CHECK("tfc_edge_vec_bwd_kernel");
+    return TFC_OK;
+}
+
+extern "C" int tfc_edge_encode_bwd2(const float* vec, int64_t n_edges, int32_t lmax, int32_t sh_normalize,
+                                    const float* bw, int32_t n_basis, float r_max, float p, const float* dsh,
+                                    const float* demb, const float* dlen, const float* gv, const float* gb,
+                                    float* g_vec, float* g_dsh, float* g_demb, float* g_dlen, float* g_bw_partial,
+                                    tfc_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    TFC_REQUIRE(n_edges >= 0, TFC_EINVAL, "tfc_edge_encode_bwd2: negative size");
+    TFC_REQUIRE(!dsh || (lmax >= 0 && lmax <= TFC_LMAX), TFC_EUNSUPPORTED, "tfc_edge_encode_bwd2: lmax=%d outside 0..%d",
+                lmax, TFC_LMAX);
+    TFC_REQUIRE(!demb || (bw && n_basis > 0 && n_basis <= 8 && r_max > 0.f), TFC_EUNSUPPORTED,
+                "tfc_edge_encode_bwd2: n_basis=%d outside 1..8", n_basis);
+    TFC_REQUIRE((!g_dsh || dsh) && (!g_demb || demb) && (!g_bw_partial || demb), TFC_EINVAL,
+                "tfc_edge_encode_bwd2: a cotangent is asked for an input that was not given");
+    const int grid = (int)tfc_edge_bwd_blocks(n_edges);
+    if (n_edges == 0) {
+        if (g_bw_partial) TFC_HIP(hipMemsetAsync(g_bw_partial, 0, sizeof(float) * n_basis, stream));
+        return TFC_OK;
+    }
+    TFC_REQUIRE(vec, TFC_EINVAL, "tfc_edge_encode_bwd2: null tensor");
+    TfcProfScope prof("tfc_edge_bwd2_kernel", stream);
+    tfc_edge_bwd2_kernel<<<grid, EDGE_BWD_BLOCK, 0, stream>>>(vec, (long)n_edges, dsh ? lmax : 0, sh_normalize, bw, n_basis,
+                                                              r_max, p, dsh, demb, dlen, gv, gb, g_vec, g_dsh, g_demb,
+                                                              g_dlen, g_bw_partial);
+    TFC_LAUNCH_CHECK("tfc_edge_bwd2_kernel");
     return TFC_OK;
 }

@@ -47,6 +47,29 @@ __device__ __forceinline__ float act_grad(int act, float x) {
     }
 }
 
+__device__ __forceinline__ float act_grad2(int act, float x) {  // second derivative
+    switch (act) {
+        case TFC_ACT_SSP: {
+            if (x > 20.f) return 0.f;
+            const float s = 1.f / (1.f + expf(-x));
+            return s * (1.f - s);
+        }
+        case TFC_ACT_SILU: {
+            const float s = 1.f / (1.f + expf(-x));
+            return s * (1.f - s) * (2.f + x * (1.f - 2.f * s));
+        }
+        case TFC_ACT_TANH: {
+            const float t = tanhf(x);
+            return -2.f * t * (1.f - t * t);
+        }
+        case TFC_ACT_SIGMOID: {
+            const float s = 1.f / (1.f + expf(-x));
+            return s * (1.f - s) * (1.f - 2.f * s);
+        }
+        default: return 0.f;  // identity, abs
+    }
+}
+
 __global__ __launch_bounds__(256) void tfc_gate_fwd_kernel(const GateSegs g, const float* __restrict__ x,
                                                            long n_rows, int d_in, int d_out,
                                                            float* __restrict__ out) {
@@ -106,6 +129,66 @@ __global__ __launch_bounds__(256) void tfc_gate_bwd_kernel(const GateSegs g, con
             }
         }
         dx[i] = v;
+    }
+}
+
+// Second order: the backward above is dx = J(x)^T gout.  Given a cotangent v of dx, autograd needs
+//   ggout = J(x) v                     (one thread per output column), and
+//   gx    = d/dx ( v^T J(x)^T gout )   (one thread per input column).
+template <bool OUT_SIDE>
+__global__ __launch_bounds__(256) void tfc_gate_bwd2_kernel(const GateSegs g, const float* __restrict__ x,
+                                                            const float* __restrict__ gout,
+                                                            const float* __restrict__ v, long n_rows, int d_in,
+                                                            int d_out, float* __restrict__ res) {
+    const int d = OUT_SIDE ? d_out : d_in;
+    const long total = n_rows * (long)d;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (long)gridDim.x * blockDim.x) {
+        const long r = i / d;
+        const int c = (int)(i - r * d);
+        const float* xr = x + r * (long)d_in;
+        const float* vr = v + r * (long)d_in;
+        const float* gr = gout + r * (long)d_out;
+        float o = 0.f;
+        for (int s = 0; s < g.n; ++s) {
+            const tfc_gate_seg sg = g.s[s];
+            if (OUT_SIDE) {
+                const int idx = c - sg.out_off;
+                if (idx < 0 || idx >= sg.count * sg.dim) continue;
+                if (sg.gate_off < 0) {
+                    o = vr[sg.in_off + idx] * sg.cst * act_grad(sg.act, xr[sg.in_off + idx]);
+                } else {
+                    const int u = idx / sg.dim;
+                    const float t = xr[sg.gate_off + u];
+                    o = sg.cst * (vr[sg.in_off + idx] * act_eval(sg.act, t) +
+                                  vr[sg.gate_off + u] * act_grad(sg.act, t) * xr[sg.in_off + idx]);
+                }
+                break;
+            } else {
+                const int idx = c - sg.in_off;
+                if (idx >= 0 && idx < sg.count * sg.dim) {
+                    if (sg.gate_off < 0) {
+                        o = vr[c] * gr[sg.out_off + idx] * sg.cst * act_grad2(sg.act, xr[c]);
+                    } else {
+                        const int u = idx / sg.dim;
+                        o = vr[sg.gate_off + u] * sg.cst * act_grad(sg.act, xr[sg.gate_off + u]) * gr[sg.out_off + idx];
+                    }
+                    break;
+                }
+                const int gu = c - sg.gate_off;
+                if (sg.gate_off >= 0 && gu >= 0 && gu < sg.count) {
+                    float vg = 0.f, gx = 0.f;
+                    for (int m = 0; m < sg.dim; ++m) {
+                        const float gg = gr[sg.out_off + gu * sg.dim + m];
+                        vg = fmaf(vr[sg.in_off + gu * sg.dim + m], gg, vg);
+                        gx = fmaf(gg, xr[sg.in_off + gu * sg.dim + m], gx);
+                    }
+                    o = sg.cst * (act_grad(sg.act, xr[c]) * vg + vr[c] * act_grad2(sg.act, xr[c]) * gx);
+                    break;
+                }
+            }
+        }
+        res[i] = o;
     }
 }
 
@@ -225,6 +308,30 @@ extern "C" int tfc_gate_bwd(const tfc_gate_seg* segs, int32_t n_segs, const floa
     TfcProfScope prof("tfc_gate_bwd_kernel", stream);
     tfc_gate_bwd_kernel<<<grid, 256, 0, stream>>>(g, x, gout, (long)n_rows, d_in, d_out, dx);
     TFC_LAUNCH_CHECK("tfc_gate_bwd_kernel");
+    return TFC_OK;
+}
+
+extern "C" int tfc_gate_bwd2(const tfc_gate_seg* segs, int32_t n_segs, const float* x, const float* gout,
+                             const float* v, int64_t n_rows, int32_t d_in, int32_t d_out, float* ggout, float* gx,
+                             tfc_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    TFC_REQUIRE(n_rows >= 0 && d_in > 0 && d_out > 0, TFC_EINVAL, "tfc_gate_bwd2: bad size");
+    GateSegs g;
+    int rc = pack_segs(segs, n_segs, d_in, d_out, &g);
+    if (rc) return rc;
+    if (n_rows == 0) return TFC_OK;
+    TFC_REQUIRE(x && gout && v && (ggout || gx), TFC_EINVAL, "tfc_gate_bwd2: null tensor");
+    TfcProfScope prof("tfc_gate_bwd2_kernel", stream);
+    if (ggout) {
+        const int grid = (int)std::min<long>((n_rows * (long)d_out + 255) / 256, 8192);
+        tfc_gate_bwd2_kernel<true><<<grid, 256, 0, stream>>>(g, x, gout, v, (long)n_rows, d_in, d_out, ggout);
+        TFC_LAUNCH_CHECK("tfc_gate_bwd2_kernel<out>");
+    }
+    if (gx) {
+        const int grid = (int)std::min<long>((n_rows * (long)d_in + 255) / 256, 8192);
+        tfc_gate_bwd2_kernel<false><<<grid, 256, 0, stream>>>(g, x, gout, v, (long)n_rows, d_in, d_out, gx);
+        TFC_LAUNCH_CHECK("tfc_gate_bwd2_kernel<in>");
+    }
     return TFC_OK;
 }
 

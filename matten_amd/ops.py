@@ -283,53 +283,105 @@ class ConvPlan:
             pass
 
 
+def _conv_fwd_raw(x, y, w, plan: ConvPlan, ordering, fwd_rows, n_out: int, scale: float):
+    x, y, w = _f32(x, "x"), _f32(y, "edge_attrs"), _f32(w, "weights")
+    E = y.shape[0]
+    if x.shape[1] != plan.d_in or y.shape[1] != plan.d_sh or w.shape[1] != plan.w_numel or w.shape[0] != E:
+        raise ValueError(
+            f"conv: shapes x{tuple(x.shape)} y{tuple(y.shape)} w{tuple(w.shape)} do not match the plan "
+            f"(d_in={plan.d_in}, d_sh={plan.d_sh}, w_numel={plan.w_numel})"
+        )
+    rp, eid, nbr = fwd_rows
+    if rp.numel() != n_out + 1:
+        raise ValueError("conv: ordering does not match the number of output rows")
+    out = torch.empty(n_out, plan.d_out, dtype=torch.float32, device=x.device)
+    M = ordering.m_matrices(plan, y, fwd_rows)
+    _lib.check(
+        _lib.lib().tfc_conv_fwd_m(
+            plan.handle(x.device), _ptr(x), _ptr(M), _ptr(w), _ptr(rp), _ptr(eid), _ptr(nbr), n_out, E,
+            float(scale), _ptr(out), _stream(),
+        )
+    )
+    return out, x, y, w
+
+
+def _conv_bwd_raw(gout, x, y, w, plan: ConvPlan, ordering, bwd_rows, scale: float, need_dy: bool):
+    gout, x, y, w = _f32(gout, "grad_output"), _f32(x, "x"), _f32(y, "edge_attrs"), _f32(w, "weights")
+    E = y.shape[0]
+    rp, eid, nbr = bwd_rows
+    dx = torch.empty_like(x)
+    dw = torch.empty_like(w)
+    dy = torch.empty_like(y) if need_dy else None
+    L = _lib.lib()
+    h = plan.handle(x.device)
+    M = ordering.m_matrices(plan, y, bwd_rows)
+    dyp = torch.empty(int(L.tfc_conv_dy_floats(h, E)), dtype=torch.float32, device=x.device) if need_dy else None
+    _lib.check(
+        L.tfc_conv_bwd_m(
+            h, _ptr(x), _ptr(M), _ptr(w), _ptr(gout), _ptr(rp), _ptr(eid), _ptr(nbr),
+            x.shape[0], E, scale, _ptr(dx), _ptr(dw), _ptr(dy), _ptr(dyp), _stream(),
+        )
+    )
+    return dx, dy, dw
+
+
+def _add(a, b):
+    return b if a is None else (a if b is None else a + b)
+
+
 class _ConvFn(torch.autograd.Function):
+    """out = T(x, y, w): the fused gather + 'uvu' product + per-node sum, trilinear in its three inputs."""
+
     @staticmethod
     def forward(ctx, x, y, w, plan: ConvPlan, ordering, fwd_rows, bwd_rows, n_out: int, scale: float):
-        x, y, w = _f32(x, "x"), _f32(y, "edge_attrs"), _f32(w, "weights")
-        E = y.shape[0]
-        if x.shape[1] != plan.d_in or y.shape[1] != plan.d_sh or w.shape[1] != plan.w_numel or w.shape[0] != E:
-            raise ValueError(
-                f"conv: shapes x{tuple(x.shape)} y{tuple(y.shape)} w{tuple(w.shape)} do not match the plan "
-                f"(d_in={plan.d_in}, d_sh={plan.d_sh}, w_numel={plan.w_numel})"
-            )
-        rp, eid, nbr = fwd_rows
-        if rp.numel() != n_out + 1:
-            raise ValueError("conv: ordering does not match the number of output rows")
-        out = torch.empty(n_out, plan.d_out, dtype=torch.float32, device=x.device)
-        M = ordering.m_matrices(plan, y, fwd_rows)
-        _lib.check(
-            _lib.lib().tfc_conv_fwd_m(
-                plan.handle(x.device), _ptr(x), _ptr(M), _ptr(w), _ptr(rp), _ptr(eid), _ptr(nbr), n_out, E,
-                float(scale), _ptr(out), _stream(),
-            )
-        )
+        out, x, y, w = _conv_fwd_raw(x, y, w, plan, ordering, fwd_rows, n_out, scale)
         ctx.save_for_backward(x, y, w)
-        ctx.plan, ctx.bwd_rows, ctx.scale, ctx.ordering = plan, bwd_rows, float(scale), ordering
+        ctx.args = (plan, ordering, fwd_rows, bwd_rows, n_out, float(scale))
         return out
 
     @staticmethod
     def backward(ctx, gout):
         x, y, w = ctx.saved_tensors
-        plan = ctx.plan
-        gout = _f32(gout, "grad_output")
-        E = y.shape[0]
+        plan, ordering, fwd_rows, bwd_rows, n_out, scale = ctx.args
         need_dy = ctx.needs_input_grad[1]
-        rp, eid, nbr = ctx.bwd_rows
-        dx = torch.empty_like(x)
-        dw = torch.empty_like(w)
-        dy = torch.empty_like(y) if need_dy else None
-        L = _lib.lib()
-        h = plan.handle(x.device)
-        M = ctx.ordering.m_matrices(plan, y, ctx.bwd_rows)
-        dyp = torch.empty(int(L.tfc_conv_dy_floats(h, E)), dtype=torch.float32, device=x.device) if need_dy else None
-        _lib.check(
-            L.tfc_conv_bwd_m(
-                h, _ptr(x), _ptr(M), _ptr(w), _ptr(gout), _ptr(rp), _ptr(eid), _ptr(nbr),
-                x.shape[0], E, ctx.scale, _ptr(dx), _ptr(dw), _ptr(dy), _ptr(dyp), _stream(),
-            )
-        )
+        if torch.is_grad_enabled():  # create_graph=True: the backward itself must be differentiable
+            dx, dy, dw = _ConvBwdFn.apply(gout, x, y, w, *ctx.args)
+            return dx, (dy if need_dy else None), dw, None, None, None, None, None, None
+        dx, dy, dw = _conv_bwd_raw(gout, x, y, w, plan, ordering, bwd_rows, scale, need_dy)
         return dx, dy, dw, None, None, None, None, None, None
+
+
+class _ConvBwdFn(torch.autograd.Function):
+    """(dx, dy, dw) = the three partial transposes of T applied to gout.  T is trilinear, so every derivative
+    of these is T or one of its transposes again with one argument replaced by the incoming cotangent: the
+    double backward (training on forces) runs on the same two kernels, to any order."""
+
+    @staticmethod
+    def forward(ctx, gout, x, y, w, plan, ordering, fwd_rows, bwd_rows, n_out, scale):
+        dx, dy, dw = _conv_bwd_raw(gout, x, y, w, plan, ordering, bwd_rows, scale, True)
+        ctx.save_for_backward(gout, x, y, w)
+        ctx.args = (plan, ordering, fwd_rows, bwd_rows, n_out, scale)
+        ctx.set_materialize_grads(False)
+        return dx, dy, dw
+
+    @staticmethod
+    def backward(ctx, ggx, ggy, ggw):
+        gout, x, y, w = ctx.saved_tensors
+        a = ctx.args
+        g_gout = g_x = g_y = g_w = None
+        if ggx is not None:  # dx = T^x(gout; y, w) with x replaced
+            g_gout = _add(g_gout, _ConvFn.apply(ggx, y, w, *a))
+            _, dy1, dw1 = _ConvBwdFn.apply(gout, ggx, y, w, *a)
+            g_y, g_w = _add(g_y, dy1), _add(g_w, dw1)
+        if ggy is not None:
+            g_gout = _add(g_gout, _ConvFn.apply(x, ggy, w, *a))
+            dx2, _, dw2 = _ConvBwdFn.apply(gout, x, ggy, w, *a)
+            g_x, g_w = _add(g_x, dx2), _add(g_w, dw2)
+        if ggw is not None:
+            g_gout = _add(g_gout, _ConvFn.apply(x, y, ggw, *a))
+            dx3, dy3, _ = _ConvBwdFn.apply(gout, x, y, ggw, *a)
+            g_x, g_y = _add(g_x, dx3), _add(g_y, dy3)
+        return g_gout, g_x, g_y, g_w, None, None, None, None, None, None
 
 
 def conv(x, y, w, plan: ConvPlan, ordering: EdgeOrdering, scale: float = 1.0, per_edge: bool = False):
@@ -343,7 +395,7 @@ def conv(x, y, w, plan: ConvPlan, ordering: EdgeOrdering, scale: float = 1.0, pe
 
 class _ScatterAddFn(torch.autograd.Function):
     """scatter_add over dim 0 as a fixed-order sum over each destination's rows; backward is a
-    row gather."""
+    row gather (whose backward is this sum again: differentiable to any order)."""
 
     @staticmethod
     def forward(ctx, src, index, dim_size: int):
@@ -362,11 +414,26 @@ class _ScatterAddFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         (index,) = ctx.saved_tensors
-        g = _f32(g, "grad_output")
-        d = g.shape[1]
-        out = torch.empty(ctx.n_src, d, dtype=torch.float32, device=g.device)
-        _lib.check(_lib.lib().tfc_gather_rows(_ptr(g), _ptr(index), ctx.n_src, g.shape[0], d, _ptr(out), _stream()))
-        return out, None, None
+        return _GatherRowsFn.apply(g, index, ctx.n_src), None, None
+
+
+class _GatherRowsFn(torch.autograd.Function):
+    """out[r] = src[index[r]] (tfc_gather_rows)."""
+
+    @staticmethod
+    def forward(ctx, src, index, n_rows: int):
+        src = _f32(src, "src")
+        d = src.shape[1]
+        out = torch.empty(n_rows, d, dtype=torch.float32, device=src.device)
+        _lib.check(_lib.lib().tfc_gather_rows(_ptr(src), _ptr(index), n_rows, src.shape[0], d, _ptr(out), _stream()))
+        ctx.save_for_backward(index)
+        ctx.n_src = src.shape[0]
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        (index,) = ctx.saved_tensors
+        return _ScatterAddFn.apply(g, index, ctx.n_src), None, None
 
 
 def scatter_add(src, index, dim_size: int):
@@ -378,7 +445,8 @@ def scatter_add(src, index, dim_size: int):
 # ======================================================================================
 
 
-def _dvec_to_dpos(dvec, ordering: EdgeOrdering):
+def _dvec_to_dpos_raw(dvec, ordering: EdgeOrdering):
+    dvec = _f32(dvec, "dvec")
     dpos = torch.empty(ordering.n_nodes, 3, dtype=torch.float32, device=dvec.device)
     if ordering.n_edges == 0:
         return dpos.zero_()
@@ -388,6 +456,49 @@ def _dvec_to_dpos(dvec, ordering: EdgeOrdering):
         _lib.lib().tfc_edge_vec_bwd(_ptr(dvec), _ptr(rps), _ptr(eids), _ptr(rpd), _ptr(eidd), ordering.n_nodes, _ptr(dpos), _stream())
     )
     return dpos
+
+
+class _ScatterVecFn(torch.autograd.Function):
+    """dpos[n] = sum_{e into n} dvec[e] - sum_{e out of n} dvec[e]: the transpose of pos -> pos[j] - pos[i]."""
+
+    @staticmethod
+    def forward(ctx, dvec, ordering: EdgeOrdering):
+        ctx.ordering = ordering
+        return _dvec_to_dpos_raw(dvec, ordering)
+
+    @staticmethod
+    def backward(ctx, g):
+        return _GatherVecFn.apply(g, ctx.ordering), None
+
+
+class _GatherVecFn(torch.autograd.Function):
+    """vec[e] = pos[j] - pos[i] (no periodic shift: the linear part of with_edge_vectors)."""
+
+    @staticmethod
+    def forward(ctx, pos, ordering: EdgeOrdering):
+        pos = _f32(pos, "pos")
+        E = ordering.n_edges
+        ctx.ordering = ordering
+        vec = torch.empty(E, 3, dtype=torch.float32, device=pos.device)
+        if E:
+            length = torch.empty(E, dtype=torch.float32, device=pos.device)
+            _lib.check(
+                _lib.lib().tfc_edge_encode_fwd(
+                    _ptr(pos), _ptr(ordering.edge_index), None, None, None, E, pos.shape[0], 1, 0, 1, None, 0, 1.0, 6.0,
+                    _ptr(vec), _ptr(length), None, None, _stream(),
+                )
+            )
+        return vec
+
+    @staticmethod
+    def backward(ctx, g):
+        return _ScatterVecFn.apply(g, ctx.ordering), None
+
+
+def _dvec_to_dpos(dvec, ordering: EdgeOrdering):
+    if torch.is_grad_enabled():
+        return _ScatterVecFn.apply(dvec, ordering)
+    return _dvec_to_dpos_raw(dvec, ordering)
 
 
 def _dvec_to_dcell(dvec, shift, batch, n_graphs: int, ordering: EdgeOrdering):
@@ -412,6 +523,101 @@ def _dvec_to_dcell(dvec, shift, batch, n_graphs: int, ordering: EdgeOrdering):
     dcell = torch.empty(n_graphs, 9, dtype=torch.float32, device=dev)
     _lib.check(L.tfc_segment_sum(_ptr(part), _ptr(rp), _ptr(nid), n_graphs, 9, _ptr(dcell), _stream()))
     return dcell.view(n_graphs, 3, 3)
+
+
+def _edge_bwd_raw(vec, length, lmax, sh_normalize, bw, r_max, p, dsh, demb, dvec_in, dlen, need_dbw):
+    """tfc_edge_encode_bwd: (dvec [E,3], dbw [B] or None) from the gradients of sh / emb / len / vec."""
+    E = vec.shape[0]
+    dvec = torch.empty_like(vec)
+    # (contiguous copies are bound to names: a temporary would be freed, and its block possibly reused by the
+    # next argument's copy, before the kernel that reads it has been queued)
+    dsh = _f32(dsh, "dsh") if dsh is not None else None
+    demb = _f32(demb, "demb") if demb is not None else None
+    dvec_in = _f32(dvec_in, "dvec") if dvec_in is not None else None
+    dlen = _f32(dlen, "dlen") if dlen is not None else None
+    B = bw.shape[0] if bw is not None else 0
+    if E == 0:
+        return dvec, (torch.zeros_like(bw) if need_dbw else None)
+    L = _lib.lib()
+    part = torch.empty(int(L.tfc_edge_bwd_blocks(E)), B, dtype=torch.float32, device=vec.device) if (need_dbw and demb is not None) else None
+    _lib.check(
+        L.tfc_edge_encode_bwd(
+            _ptr(vec), _ptr(length), E, max(lmax, 0), 1 if sh_normalize else 0, _ptr(bw) if demb is not None else None,
+            B if demb is not None else 0, float(r_max), float(p), _ptr(dsh), _ptr(demb), _ptr(dvec_in), _ptr(dlen), _ptr(dvec),
+            _ptr(part), _stream(),
+        )
+    )
+    dbw = None
+    if need_dbw:
+        dbw = part.sum(dim=0) if part is not None else torch.zeros_like(bw)  # second stage of the fixed-shape two-stage sum
+    return dvec, dbw
+
+
+class _EdgeBwdFn(torch.autograd.Function):
+    """The backward of the per-edge encoders as a differentiable op (double backward, training on forces):
+    (dvec, dbw) = gradient of phi = <dsh, Y(vec)> + <demb, emb(|vec|, bw)> + <dlen, |vec|> + <dvec_in, vec>.
+    Its own backward is one dual-number pass (tfc_edge_encode_bwd2)."""
+
+    @staticmethod
+    def forward(ctx, vec, bw, dsh, demb, dlen, dvec_in, lmax: int, sh_normalize: bool, r_max: float, p: float):
+        vec = _f32(vec, "edge_vectors")
+        bw = _f32(bw, "bessel_weights") if bw is not None else None
+        dvec, dbw = _edge_bwd_raw(vec, None, lmax, sh_normalize, bw, r_max, p, dsh, demb, dvec_in, dlen, bw is not None)
+        ctx.save_for_backward(vec, bw, dsh, demb, dlen)
+        ctx.args = (lmax, bool(sh_normalize), float(r_max), float(p), dvec_in is not None)
+        ctx.set_materialize_grads(False)
+        if dbw is None:
+            dbw = torch.zeros(0, dtype=torch.float32, device=vec.device)
+        return dvec, dbw
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, gv, gb):
+        vec, bw, dsh, demb, dlen = ctx.saved_tensors
+        lmax, sh_normalize, r_max, p, has_dvec_in = ctx.args
+        E = vec.shape[0]
+        dev = vec.device
+        if bw is None or demb is None or gb is None or gb.numel() == 0:
+            gb = None
+        if gv is None and gb is None:
+            return (None,) * 10
+        gv = _f32(gv, "gv") if gv is not None else None
+        gb = _f32(gb, "gb") if gb is not None else None
+        dsh_c = _f32(dsh, "dsh") if dsh is not None else None
+        demb_c = _f32(demb, "demb") if demb is not None else None
+        dlen_c = _f32(dlen, "dlen") if dlen is not None else None
+        S = (max(lmax, 0) + 1) ** 2
+        B = bw.shape[0] if (bw is not None and demb is not None) else 0
+        L = _lib.lib()
+        g_vec = torch.empty_like(vec)
+        g_dsh = torch.empty(E, S, dtype=torch.float32, device=dev) if dsh is not None else None
+        g_demb = torch.empty(E, B, dtype=torch.float32, device=dev) if demb is not None else None
+        g_dlen = torch.empty(E, dtype=torch.float32, device=dev) if dlen is not None else None
+        part = torch.empty(int(L.tfc_edge_bwd_blocks(E)), B, dtype=torch.float32, device=dev) if B else None
+        if E:
+            _lib.check(
+                L.tfc_edge_encode_bwd2(
+                    _ptr(vec), E, max(lmax, 0), 1 if sh_normalize else 0, _ptr(bw) if B else None, B, r_max, p, _ptr(dsh_c),
+                    _ptr(demb_c), _ptr(dlen_c), _ptr(gv), _ptr(gb), _ptr(g_vec), _ptr(g_dsh), _ptr(g_demb), _ptr(g_dlen),
+                    _ptr(part), _stream(),
+                )
+            )
+        g_bw = None
+        if bw is not None:
+            g_bw = part.sum(dim=0) if (part is not None and E) else torch.zeros_like(bw)
+        return g_vec, g_bw, g_dsh, g_demb, g_dlen, (gv if has_dvec_in else None), None, None, None, None
+
+
+def _edge_bwd(vec, length, lmax, sh_normalize, bw, r_max, p, dsh, demb, dvec_in, dlen, need_dbw):
+    """(dvec, dbw): raw kernel, or - when the caller wants a graph of the backward - the differentiable op."""
+    if torch.is_grad_enabled():
+        dvec, dbw = _EdgeBwdFn.apply(vec, bw if demb is not None else None, dsh, demb, dlen, dvec_in, lmax, sh_normalize, r_max, p)
+        if not need_dbw:
+            dbw = None
+        elif demb is None:
+            dbw = torch.zeros_like(bw)
+        return dvec, dbw
+    return _edge_bwd_raw(vec, length, lmax, sh_normalize, bw, r_max, p, dsh, demb, dvec_in, dlen, need_dbw)
 
 
 class _EdgeGeometryFn(torch.autograd.Function):
@@ -457,21 +663,11 @@ class _EdgeGeometryFn(torch.autograd.Function):
     def backward(ctx, dvec_in, dlen, dsh=None):
         vec, length = ctx.saved_tensors
         E = vec.shape[0]
-        dvec = torch.empty_like(vec)
-        # (contiguous copies are bound to names: a temporary would be freed, and its block possibly reused by the
-        # next argument's copy, before the kernel that reads it has been queued)
-        dsh = _f32(dsh, "dsh") if dsh is not None else None
-        dvec_in = _f32(dvec_in, "dvec") if dvec_in is not None else None
-        dlen = _f32(dlen, "dlen") if dlen is not None else None
-        if E:
-            _lib.check(
-                _lib.lib().tfc_edge_encode_bwd(
-                    _ptr(vec), _ptr(length), E, max(ctx.lmax, 0), 1 if ctx.sh_normalize else 0, None, 0, 1.0, 6.0,
-                    _ptr(dsh), None, _ptr(dvec_in), _ptr(dlen), _ptr(dvec), None, _stream(),
-                )
-            )
+        dvec, _ = _edge_bwd(vec, length, ctx.lmax, ctx.sh_normalize, None, 1.0, 6.0, dsh, None, dvec_in, dlen, False)
         dcell = None
         if ctx.needs_input_grad[2] and ctx.cell_args is not None:
+            if torch.is_grad_enabled():
+                raise NotImplementedError("matten_amd: double backward through the gradient of `cell` is not built")
             shift, batch, G, _ = ctx.cell_args
             dcell = _dvec_to_dcell(dvec, shift, batch, G, ctx.ordering) if E else torch.zeros(G, 3, 3, dtype=torch.float32, device=vec.device)
         return _dvec_to_dpos(dvec, ctx.ordering), None, dcell, None, None, None, None
@@ -508,15 +704,7 @@ class _ShFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dsh):
         (vec,) = ctx.saved_tensors
-        dvec = torch.empty_like(vec)
-        dsh = _f32(dsh, "dsh")
-        if vec.shape[0]:
-            _lib.check(
-                _lib.lib().tfc_edge_encode_bwd(
-                    _ptr(vec), None, vec.shape[0], ctx.lmax, 1 if ctx.normalize else 0, None, 0, 1.0, 6.0,
-                    _ptr(dsh), None, None, None, _ptr(dvec), None, _stream(),
-                )
-            )
+        dvec, _ = _edge_bwd(vec, None, ctx.lmax, ctx.normalize, None, 1.0, 6.0, dsh, None, None, None, False)
         return dvec, None, None
 
 
@@ -547,22 +735,7 @@ class _RadialFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, demb):
         vec, length, bw = ctx.saved_tensors
-        E, B = vec.shape[0], bw.shape[0]
-        dvec = torch.empty_like(vec)
-        dbw = None
-        if E == 0:
-            return dvec, None, torch.zeros_like(bw) if ctx.needs_input_grad[2] else None, None, None
-        nb = int(_lib.lib().tfc_edge_bwd_blocks(E))
-        part = torch.empty(nb, B, dtype=torch.float32, device=vec.device) if ctx.needs_input_grad[2] else None
-        demb = _f32(demb, "demb")
-        _lib.check(
-            _lib.lib().tfc_edge_encode_bwd(
-                _ptr(vec), _ptr(length), E, 0, 1, _ptr(bw), B, ctx.r_max, ctx.p, None, _ptr(demb), None,
-                None, _ptr(dvec), _ptr(part), _stream(),
-            )
-        )
-        if part is not None:
-            dbw = part.sum(dim=0)  # second stage of the fixed-shape two-stage sum
+        dvec, dbw = _edge_bwd(vec, length, 0, True, bw, ctx.r_max, ctx.p, None, demb, None, None, ctx.needs_input_grad[2])
         return dvec, None, dbw, None, None
 
 
@@ -751,6 +924,32 @@ def _linear_ins(spec: "LinearSpec"):
     return arr
 
 
+def _linear_in_blocks(spec: "LinearSpec"):
+    return tuple(sorted({(in_off, mi, d) for in_off, mi, _, _, d, _, _ in spec.instructions}))
+
+
+def _linear_bwd_raw(spec: "LinearSpec", n: int, xt, g, weight, need_dx: bool, need_dw: bool):
+    """(dx, dw) of o3.Linear from the channel-contiguous copy `xt` of its input and the output gradient."""
+    g = _f32(g, "grad_output")
+    dx = dw = None
+    if need_dx:
+        dx = (torch.empty if spec.in_covered else torch.zeros)(n, spec.d_in, dtype=torch.float32, device=g.device)
+    if need_dw:
+        dw = torch.empty(spec.weight_numel, dtype=torch.float32, device=g.device)
+    if not spec.instructions:
+        return dx, (dw.zero_() if dw is not None else None)
+    # (all blocks of the row, not only the ones reached: the copy is then shared with the other
+    # consumer of the same gradient, see _ir_transpose)
+    gt = _ir_transpose(g, spec.out_blocks or [(out_off, mo, d) for _, _, out_off, mo, d, _, _ in spec.instructions])
+    ins = _linear_ins(spec)
+    L = _lib.lib()
+    need = int(L.tfc_linear_workspace_floats(ins, len(ins), n)) if dw is not None else 0
+    ws = _gemm_workspace(need) if need > 0 else None
+    _lib.check(L.tfc_linear_bwd(ins, len(ins), _ptr(xt), None, _ptr(weight), n, spec.d_in, spec.d_out, spec.weight_numel,
+                                _ptr(gt), 1, _ptr(dx), _ptr(dw), _ptr(ws), ws.numel() if ws is not None else 0, _stream()))
+    return dx, dw
+
+
 class _LinearFn(torch.autograd.Function):
     """o3.Linear through tfc_linear_fwd / tfc_linear_bwd: the products run on channel-contiguous copies
     of the input and of the output gradient, every instruction, whatever its l, being the same plain
@@ -769,32 +968,53 @@ class _LinearFn(torch.autograd.Function):
             ins = _linear_ins(spec)
             _lib.check(_lib.lib().tfc_linear_fwd(ins, len(ins), _ptr(x), _ptr(weight), n, spec.d_in, spec.d_out, spec.weight_numel,
                                                  _ptr(xt), _ptr(out), _stream()))
-        ctx.save_for_backward(xt, weight)
+        ctx.save_for_backward(xt, weight, x)
         ctx.spec, ctx.n = spec, n
         return out
 
     @staticmethod
     def backward(ctx, g):
-        xt, weight = ctx.saved_tensors
+        xt, weight, x = ctx.saved_tensors
         spec, n = ctx.spec, ctx.n
+        if torch.is_grad_enabled():  # create_graph=True
+            dx, dw = _LinearBwdFn.apply(g, x, weight, spec, ctx.needs_input_grad[0], ctx.needs_input_grad[1])
+            return dx, (dw.view_as(weight) if dw is not None else None), None
+        dx, dw = _linear_bwd_raw(spec, n, xt, g, weight, ctx.needs_input_grad[0], ctx.needs_input_grad[1])
+        return dx, (dw.view_as(weight) if dw is not None else None), None
+
+
+class _LinearBwdFn(torch.autograd.Function):
+    """(dx, dw) of o3.Linear as a differentiable op.  The layer is bilinear in (x, W), so the derivatives of
+    its two transposes are the layer and its transposes again (same kernels, any order)."""
+
+    @staticmethod
+    def forward(ctx, g, x, weight, spec: LinearSpec, need_dx: bool, need_dw: bool):
         g = _f32(g, "grad_output")
-        dx = dw = None
-        if ctx.needs_input_grad[0]:
-            dx = (torch.empty if spec.in_covered else torch.zeros)(n, spec.d_in, dtype=torch.float32, device=g.device)
-        if ctx.needs_input_grad[1]:
-            dw = torch.empty_like(weight)
-        if not spec.instructions:
-            return dx, (dw.zero_() if dw is not None else None), None
-        # (all blocks of the row, not only the ones reached: the copy is then shared with the other
-        # consumer of the same gradient, see _ir_transpose)
-        gt = _ir_transpose(g, spec.out_blocks or [(out_off, mo, d) for _, _, out_off, mo, d, _, _ in spec.instructions])
-        ins = _linear_ins(spec)
-        L = _lib.lib()
-        need = int(L.tfc_linear_workspace_floats(ins, len(ins), n)) if dw is not None else 0
-        ws = _gemm_workspace(need) if need > 0 else None
-        _lib.check(L.tfc_linear_bwd(ins, len(ins), _ptr(xt), None, _ptr(weight), n, spec.d_in, spec.d_out, spec.weight_numel,
-                                    _ptr(gt), 1, _ptr(dx), _ptr(dw), _ptr(ws), ws.numel() if ws is not None else 0, _stream()))
-        return dx, dw, None
+        n = g.shape[0]
+        xt = None
+        if need_dw:
+            x = _f32(x, "x")
+            xt = _ir_transpose(x, _linear_in_blocks(spec)) if spec.instructions else None
+        if need_dx:
+            weight = _f32(weight, "weight")
+        dx, dw = _linear_bwd_raw(spec, n, xt, g, weight if need_dx else None, need_dx, need_dw)
+        ctx.save_for_backward(g, x if need_dw else None, weight if need_dx else None)
+        ctx.spec, ctx.need = spec, (need_dx, need_dw)
+        ctx.set_materialize_grads(False)
+        return dx, dw
+
+    @staticmethod
+    def backward(ctx, ggx, ggw):
+        g, x, weight = ctx.saved_tensors
+        spec = ctx.spec
+        g_g = g_x = g_w = None
+        if ggx is not None:  # dx = g W^T
+            g_g = _add(g_g, _LinearFn.apply(ggx, weight, spec))
+            g_w = _LinearBwdFn.apply(g, ggx, None, spec, False, True)[1].view_as(weight)
+        if ggw is not None:  # dw = x^T g
+            g_g = _add(g_g, _LinearFn.apply(x, ggw.reshape(-1), spec))
+            g_x = _LinearBwdFn.apply(g, None, ggw.reshape(-1), spec, True, False)[0]
+        return g_g, g_x, g_w, None, None, None
 
 
 def linear(x, weight, spec: LinearSpec):
@@ -858,6 +1078,20 @@ class _RadialMlpFn(torch.autograd.Function):
     def backward(ctx, g):
         nl = ctx.n_layers
         hs, ws = ctx.saved_tensors[:nl], ctx.saved_tensors[nl:]  # hs[0] = x, hs[i] = output of layer i-1
+        if torch.is_grad_enabled():
+            # create_graph=True: rebuild the network from ops that are differentiable to any order (dense products
+            # and the shifted softplus as a one-segment gate, all on the same kernels) and let autograd derive a
+            # backward that can be differentiated again
+            need = [i for i in range(1 + nl) if ctx.needs_input_grad[0 if i == 0 else 2 + i]]
+            if not need:
+                return (None,) * (3 + nl)
+            with torch.enable_grad():
+                out = _radial_mlp_composite(hs[0], ws, ctx.act_cst)
+                grads = torch.autograd.grad(out, [([hs[0]] + list(ws))[i] for i in need], g, create_graph=True, allow_unused=True)
+            res = [None] * (1 + nl)
+            for i, gr in zip(need, grads):
+                res[i] = gr
+            return (res[0], None, None, *res[1:])
         g = _f32(g, "grad_output")
         E = g.shape[0]
         dev = g.device
@@ -875,6 +1109,55 @@ class _RadialMlpFn(torch.autograd.Function):
             _ptr(wsp), wsp.numel() if wsp is not None else 0, _stream(),
         ))
         return (dx, None, None, *dws)
+
+
+class _MatmulFn(torch.autograd.Function):
+    """C = alpha op(a) op(b) on the fp32 MFMA GEMM; a, b row-major 2-D, op = transpose when flagged.  Its
+    backward is two more such products."""
+
+    @staticmethod
+    def forward(ctx, a, b, ta: bool, tb: bool, alpha: float):
+        a, b = _f32(a, "a"), _f32(b, "b")
+        m, k = (a.shape[1], a.shape[0]) if ta else (a.shape[0], a.shape[1])
+        k2, n = (b.shape[1], b.shape[0]) if tb else (b.shape[0], b.shape[1])
+        if k != k2:
+            raise ValueError(f"matmul: inner sizes {k} and {k2} differ")
+        c = torch.empty(m, n, dtype=torch.float32, device=a.device)
+        if m and n:
+            if k == 0:
+                c.zero_()
+            else:
+                _gemm(
+                    m, n, k, _p(a), _p(b), _p(c),
+                    a1_r=_lin(1) if ta else _lin(a.shape[1]), a1_k=_lin(a.shape[1]) if ta else _lin(1),
+                    b_k=_lin(1) if tb else _lin(b.shape[1]), b_j=_lin(b.shape[1]) if tb else _lin(1),
+                    c_r=_lin(n), c_j=_lin(1), alpha=alpha, tag=b"gemm_matmul",
+                )
+        ctx.save_for_backward(a, b)
+        ctx.args = (ta, tb, float(alpha))
+        return c
+
+    @staticmethod
+    def backward(ctx, g):
+        a, b = ctx.saved_tensors
+        ta, tb, alpha = ctx.args
+        da = db = None
+        if ctx.needs_input_grad[0]:
+            da = _MatmulFn.apply(b, g, tb, True, alpha) if ta else _MatmulFn.apply(g, b, False, not tb, alpha)
+        if ctx.needs_input_grad[1]:
+            db = _MatmulFn.apply(g, a, True, ta, alpha) if tb else _MatmulFn.apply(a, g, not ta, False, alpha)
+        return da, db, None, None, None
+
+
+def _radial_mlp_composite(x, ws, act_cst: float):
+    """The radial network out of ops that are differentiable to any order (used for double backward)."""
+    h = x
+    for i, w in enumerate(ws):
+        h = _MatmulFn.apply(h, w, False, False, 1.0 / math.sqrt(w.shape[0]))
+        if i < len(ws) - 1:
+            d = w.shape[1]
+            h = _GateFn.apply(h, GateSpec(d_in=d, d_out=d, segs=((0, 0, d, 1, -1, _lib.ACT["ssp"], float(act_cst)),)))
+    return h
 
 
 def radial_mlp(x, weights: Sequence[torch.Tensor], act_cst: float, pre=None):
@@ -1103,6 +1386,12 @@ class _FctpFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         spec = ctx.spec
+        if torch.is_grad_enabled():
+            # create_graph=True: the dense, differentiable form of the backward (exactly the same sums; with
+            # promised classes the attribute gradient is then the per-node one, whose class sums are equal)
+            x, a, weight = ctx.saved_tensors[:3]
+            dx, da, dw = _FctpBwdFn.apply(g, x, a, weight, spec, *ctx.needs_input_grad[:3])
+            return dx, da, (dw.view_as(weight) if dw is not None else None), None, (g if ctx.has_base else None), None
         g = _f32(g, "grad_output")
         if ctx.low is None:
             x, a, weight = ctx.saved_tensors
@@ -1163,6 +1452,49 @@ class _FctpFn(torch.autograd.Function):
         return dx, da, dw, None, (g if ctx.has_base else None), None
 
 
+class _FctpBwdFn(torch.autograd.Function):
+    """(dx, da, dw) of the self connection as a differentiable op (dense route).  The product is trilinear in
+    (x, a, W): every derivative of its transposes is the product or a transpose again."""
+
+    @staticmethod
+    def forward(ctx, g, x, a, weight, spec: FctpSpec, need_dx: bool, need_da: bool, need_dw: bool):
+        g = _f32(g, "grad_output")
+        x, a, weight = _f32(x, "x"), _f32(a, "node_attrs"), _f32(weight, "weight")
+        n = x.shape[0]
+        dev = x.device
+        gt = _ir_transpose(g, spec.out_blocks or [(oo, mw, d) for _, _, _, _, oo, mw, d, _, _ in spec.instructions])
+        dx = (torch.empty if spec.x_covered else torch.zeros)(n, spec.d_x, dtype=torch.float32, device=dev) if need_dx else None
+        da = (torch.empty if spec.a_covered else torch.zeros)(n, spec.d_a, dtype=torch.float32, device=dev) if need_da else None
+        dw = torch.empty(spec.weight_numel, dtype=torch.float32, device=dev) if need_dw else None
+        if dx is not None or da is not None or dw is not None:
+            _fctp_bwd(n, x, a, spec.d_a, weight.reshape(-1), gt, spec, spec.instructions, dx=dx, dw=dw, da=da)
+        ctx.save_for_backward(g, x, a, weight)
+        ctx.spec = spec
+        ctx.set_materialize_grads(False)
+        return dx, da, dw
+
+    @staticmethod
+    def backward(ctx, ggx, gga, ggw):
+        g, x, a, weight = ctx.saved_tensors
+        spec = ctx.spec
+        fwd = lambda x_, a_, w_: _FctpFn.apply(x_, a_, w_.reshape(-1), spec, None, None)  # noqa: E731
+        bwd = lambda x_, a_, w_, *need: _FctpBwdFn.apply(g, x_, a_, w_.reshape(-1), spec, *need)  # noqa: E731
+        g_g = g_x = g_a = g_w = None
+        if ggx is not None:
+            g_g = _add(g_g, fwd(ggx, a, weight))
+            _, da1, dw1 = bwd(ggx, a, weight, False, True, True)
+            g_a, g_w = _add(g_a, da1), _add(g_w, dw1)
+        if gga is not None:
+            g_g = _add(g_g, fwd(x, gga, weight))
+            dx2, _, dw2 = bwd(x, gga, weight, True, False, True)
+            g_x, g_w = _add(g_x, dx2), _add(g_w, dw2)
+        if ggw is not None:
+            g_g = _add(g_g, fwd(x, a, ggw))
+            dx3, da3, _ = bwd(x, a, ggw, True, True, False)
+            g_x, g_a = _add(g_x, dx3), _add(g_a, da3)
+        return g_g, g_x, g_a, (g_w.view_as(weight) if g_w is not None else None), None, None, None, None
+
+
 def fctp(x, a, weight, spec: FctpSpec, base: Optional[torch.Tensor] = None, low_rank: bool = True,
          classes: Optional[torch.Tensor] = None):
     """FullyConnectedTensorProduct(x, a) with scalar `a`; when `base` is given the result is
@@ -1203,11 +1535,42 @@ class _GateFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         (x,) = ctx.saved_tensors
-        spec = ctx.spec
+        if torch.is_grad_enabled():  # create_graph=True
+            return _GateBwdFn.apply(x, g, ctx.spec), None
+        return _gate_bwd_raw(x, g, ctx.spec), None
+
+
+def _gate_bwd_raw(x, g, spec: GateSpec):
+    g = _f32(g, "grad_output")
+    dx = torch.empty_like(x)
+    _lib.check(_lib.lib().tfc_gate_bwd(spec.c_array(), len(spec.segs), _ptr(x), _ptr(g), x.shape[0], spec.d_in, spec.d_out, _ptr(dx), _stream()))
+    return dx
+
+
+class _GateBwdFn(torch.autograd.Function):
+    """dx = J(x)^T g of the gate as a differentiable op; its backward is tfc_gate_bwd2 (second derivatives of the
+    activations).  Third order is not built."""
+
+    @staticmethod
+    def forward(ctx, x, g, spec: GateSpec):
+        x = _f32(x, "x")
         g = _f32(g, "grad_output")
-        dx = torch.empty_like(x)
-        _lib.check(_lib.lib().tfc_gate_bwd(spec.c_array(), len(spec.segs), _ptr(x), _ptr(g), x.shape[0], spec.d_in, spec.d_out, _ptr(dx), _stream()))
-        return dx, None
+        ctx.save_for_backward(x, g)
+        ctx.spec = spec
+        return _gate_bwd_raw(x, g, spec)
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, v):
+        x, g = ctx.saved_tensors
+        spec = ctx.spec
+        v = _f32(v, "cotangent")
+        gx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        gg = torch.empty_like(g) if ctx.needs_input_grad[1] else None
+        if gx is not None or gg is not None:
+            _lib.check(_lib.lib().tfc_gate_bwd2(spec.c_array(), len(spec.segs), _ptr(x), _ptr(g), _ptr(v), x.shape[0], spec.d_in,
+                                                spec.d_out, _ptr(gg), _ptr(gx), _stream()))
+        return gx, gg, None
 
 
 def gate(x, spec: GateSpec):
@@ -1228,6 +1591,7 @@ class _NormActFn(torch.autograd.Function):
         return out
 
     @staticmethod
+    @torch.autograd.function.once_differentiable  # (the second order of the norm activation is not built: raises)
     def backward(ctx, g):
         (x,) = ctx.saved_tensors
         spec, eps_squared, normalize = ctx.args
