@@ -217,6 +217,17 @@ int tfc_conv_bwd_m(const tfc_conv_plan* plan, const float* x, const float* M, co
                    int64_t n_edges, float scale, float* dx, float* dw, float* dy, float* dyp,
                    tfc_stream_t stream);
 
+/* tfc_conv_fwd_m with the LAST layer of the radial network folded in (eigenn/nn/utils.py:262 is where the
+ * weights are born, :265 where they are consumed): the per-edge weights are never materialised,
+ *     w[e, j] = alpha * sum_k h[e, k] * w_last[k, j],   h [E, hidden] the last hidden activations,
+ *     w_last [hidden, w_numel] row-major, alpha = 1 / sqrt(hidden).
+ * Forward only (inference; training needs w for the backward, see DESIGN.md §4 for the measurement that keeps
+ * the unfused call as the default).  hidden = 64 only (TFC_EUNSUPPORTED otherwise). */
+int tfc_conv_fwd_fused_m(const tfc_conv_plan* plan, const float* x, const float* M, const float* h,
+                         const float* w_last, int32_t hidden, float alpha, const int32_t* row_ptr,
+                         const int32_t* eid, const int32_t* nbr, int64_t n_nodes, int64_t n_edges, float scale,
+                         float* out, tfc_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------
  * Per-edge encoders.
  *

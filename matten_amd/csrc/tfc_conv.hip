@@ -214,6 +214,123 @@ __global__ __launch_bounds__(256) void tfc_conv_fwd_kernel(
 }
 
 // ------------------------------------------------------------------------------------------
+// Forward with the radial network's LAST layer folded in ("measure both"): the per-edge
+// weights w [E, W] are never read; each wave forms the 64 weights of its (path, chunk) for an edge from the last
+// hidden activations h [E, H] (wave-uniform: scalar loads) and its own H x 64 slice of W_L, one column per lane
+// held in registers:  w[e, w_off + u] = alpha * sum_k h[e, k] * W_L[k, w_off + u].
+// Algorithmic bytes per edge drop by 4 W (the w row) and grow by 4 H (the h row); the price is H extra FMAs and
+// H scalar operands per (edge, path), and H more live registers.  H = 64 only.
+template <int L1, int L3, int UNR, int H>
+__device__ __forceinline__ void fwdw_edges(const float* __restrict__ xb, const float* __restrict__ h,
+                                           const float* __restrict__ Mb, int ev, int sv, int j0, int k, int d_in,
+                                           int msz, const float (&wc)[H], float (&acc)[2 * L3 + 1]) {
+    constexpr int D1 = 2 * L1 + 1, D3 = 2 * L3 + 1;
+    float xv[UNR][D1], wv[UNR];
+#pragma unroll
+    for (int j = 0; j < UNR; ++j) {
+        const int s = __builtin_amdgcn_readlane(sv, j0 + j);
+        const float* xr = xb + (size_t)s * d_in;
+#pragma unroll
+        for (int m1 = 0; m1 < D1; ++m1) xv[j][m1] = xr[m1];
+    }
+#pragma unroll
+    for (int j = 0; j < UNR; ++j) {
+        const int e = __builtin_amdgcn_readlane(ev, j0 + j);
+        const float* hr = h + (size_t)e * H;
+        float p0 = 0.f, p1 = 0.f, p2 = 0.f, p3 = 0.f;  // four chains instead of one of length H
+#pragma unroll
+        for (int q = 0; q < H; q += 4) {
+            p0 = fmaf(hr[q], wc[q], p0);
+            p1 = fmaf(hr[q + 1], wc[q + 1], p1);
+            p2 = fmaf(hr[q + 2], wc[q + 2], p2);
+            p3 = fmaf(hr[q + 3], wc[q + 3], p3);
+        }
+        wv[j] = (p0 + p1) + (p2 + p3);
+    }
+#pragma unroll
+    for (int j = 0; j < UNR; ++j) {
+        const float* Mk = Mb + (size_t)(k + j) * msz;
+#pragma unroll
+        for (int m3 = 0; m3 < D3; ++m3) {
+            float z = 0.f;
+#pragma unroll
+            for (int m1 = 0; m1 < D1; ++m1) z = fmaf(Mk[m1 * D3 + m3], xv[j][m1], z);
+            acc[m3] = fmaf(wv[j], z, acc[m3]);
+        }
+    }
+}
+
+template <int L1, int L3, int H>
+__device__ __forceinline__ void fwdw_item(const float* __restrict__ x, const float* __restrict__ h,
+                                          const float* __restrict__ wl, const float* __restrict__ M,
+                                          const int* __restrict__ eid, const int* __restrict__ nbr, int beg, int end,
+                                          const PathDev p, int u, bool active, int node, int d_in, int d_out,
+                                          int w_numel, int msz, float scale, float alpha, float* __restrict__ out) {
+    constexpr int D1 = 2 * L1 + 1, D3 = 2 * L3 + 1;
+    constexpr int UNR = D1 <= 3 ? 4 : 2;
+    const int lane = threadIdx.x & 63;
+    const int uu = active ? u : 0;
+    const float* xb = x + p.x_off + uu * D1;
+    const float* Mb = M + p.m_off;
+    float wc[H];
+#pragma unroll
+    for (int q = 0; q < H; ++q) wc[q] = alpha * wl[(size_t)q * w_numel + p.w_off + uu];  // coalesced over lanes
+    float acc[D3];
+#pragma unroll
+    for (int m3 = 0; m3 < D3; ++m3) acc[m3] = 0.f;
+    for (int c0 = beg; c0 < end; c0 += 64) {
+        const int cn = end - c0 < 64 ? end - c0 : 64;
+        const int kl = c0 + (lane < cn ? lane : cn - 1);
+        const int ev = eid[kl], sv = nbr[kl];
+        int j = 0;
+        for (; j + UNR <= cn; j += UNR) fwdw_edges<L1, L3, UNR, H>(xb, h, Mb, ev, sv, j, c0 + j, d_in, msz, wc, acc);
+        for (; j < cn; ++j) fwdw_edges<L1, L3, 1, H>(xb, h, Mb, ev, sv, j, c0 + j, d_in, msz, wc, acc);
+    }
+    if (active) {
+        const float cs = p.coeff * scale;
+        float* o = out + (size_t)node * d_out + p.out_off + u * D3;
+#pragma unroll
+        for (int m3 = 0; m3 < D3; ++m3) o[m3] = cs * acc[m3];
+    }
+}
+
+__global__ __launch_bounds__(256) void tfc_conv_fwd_fused_kernel(
+    const float* __restrict__ x, const float* __restrict__ h, const float* __restrict__ wl,
+    const float* __restrict__ M, const int* __restrict__ row_ptr, const int* __restrict__ eid,
+    const int* __restrict__ nbr, const PathDev* __restrict__ paths, const FwdItem* __restrict__ items, int n_items,
+    long n_tasks, int d_in, int d_out, int w_numel, int msz, float scale, float alpha, float* __restrict__ out,
+    int n_nodes, int group) {
+    const unsigned vb = tfc_xcd_remap(blockIdx.x, gridDim.x);
+    const int wave = tfc_uniform((int)(threadIdx.x >> 6));
+    const int lane = threadIdx.x & 63;
+    const long task = (long)vb * 4 + wave;
+    if (task >= n_tasks) return;
+    int node, item;
+    tfc_task_split(task, n_items, n_nodes, group, node, item);
+    node = tfc_uniform(node);
+    item = tfc_uniform(item);
+    const FwdItem it = items[item];
+    const PathDev p = paths[it.path];
+    const int u = it.chunk * 64 + lane;
+    const bool active = u < p.mul;
+    const int beg = tfc_uniform(row_ptr[node]);
+    const int end = tfc_uniform(row_ptr[node + 1]);
+#define TFC_FWDW_CASE(A, B)                                                                               \
+    case (A)*4 + (B):                                                                                     \
+        fwdw_item<A, B, 64>(x, h, wl, M, eid, nbr, beg, end, p, u, active, node, d_in, d_out, w_numel, msz, \
+                            scale, alpha, out);                                                           \
+        break;
+    switch (p.l1 * 4 + p.l3) {
+        TFC_FWDW_CASE(0, 0) TFC_FWDW_CASE(0, 1) TFC_FWDW_CASE(0, 2) TFC_FWDW_CASE(0, 3)
+        TFC_FWDW_CASE(1, 0) TFC_FWDW_CASE(1, 1) TFC_FWDW_CASE(1, 2) TFC_FWDW_CASE(1, 3)
+        TFC_FWDW_CASE(2, 0) TFC_FWDW_CASE(2, 1) TFC_FWDW_CASE(2, 2) TFC_FWDW_CASE(2, 3)
+        TFC_FWDW_CASE(3, 0) TFC_FWDW_CASE(3, 1) TFC_FWDW_CASE(3, 2) TFC_FWDW_CASE(3, 3)
+        default: break;
+    }
+#undef TFC_FWDW_CASE
+}
+
+// ------------------------------------------------------------------------------------------
 // Backward.  Centre node = sender: its own row x[n] is fixed for the whole item, the upstream
 // gradient rows gout[receiver] are gathered.
 // ------------------------------------------------------------------------------------------
@@ -723,6 +840,32 @@ extern "C" int tfc_conv_fwd_m(const tfc_conv_plan* pl, const float* x, const flo
             pl->w_numel, pl->msz, scale, out, (int)n_nodes, conv_group(0, n_nodes));
     }
     TFC_LAUNCH_CHECK("tfc_conv_fwd_kernel");
+    return TFC_OK;
+}
+
+extern "C" int tfc_conv_fwd_fused_m(const tfc_conv_plan* pl, const float* x, const float* M, const float* h,
+                                    const float* w_last, int32_t hidden, float alpha, const int32_t* row_ptr,
+                                    const int32_t* eid, const int32_t* nbr, int64_t n_nodes, int64_t n_edges,
+                                    float scale, float* out, tfc_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    TFC_REQUIRE(pl, TFC_EINVAL, "tfc_conv_fwd_fused: null plan");
+    TFC_REQUIRE(hidden == 64, TFC_EUNSUPPORTED, "tfc_conv_fwd_fused: hidden width %d (built for 64)", hidden);
+    TFC_REQUIRE(n_nodes >= 0 && n_edges >= 0, TFC_EINVAL, "tfc_conv_fwd_fused: negative size");
+    TFC_REQUIRE(n_nodes < (1LL << 31) && n_edges < (1LL << 31), TFC_EUNSUPPORTED,
+                "tfc_conv_fwd_fused: more than 2^31 nodes or edges");
+    if (n_nodes == 0) return TFC_OK;
+    TFC_REQUIRE(x && out && row_ptr && w_last, TFC_EINVAL, "tfc_conv_fwd_fused: null tensor");
+    TFC_REQUIRE(n_edges == 0 || (M && h && eid && nbr), TFC_EINVAL, "tfc_conv_fwd_fused: null tensor");
+    const long n_tasks = (long)n_nodes * pl->n_fwd_items;
+    const long n_blocks = (n_tasks + 3) / 4;
+    TFC_REQUIRE(n_blocks < (1LL << 31), TFC_EUNSUPPORTED, "tfc_conv_fwd_fused: grid too large");
+    {
+        TfcProfScope prof("tfc_conv_fwd_fused_kernel", stream);
+        tfc_conv_fwd_fused_kernel<<<(unsigned)n_blocks, 256, 0, stream>>>(
+            x, h, w_last, M, row_ptr, eid, nbr, pl->paths, pl->fwd_items, pl->n_fwd_items, n_tasks, pl->d_in,
+            pl->d_out, pl->w_numel, pl->msz, scale, alpha, out, (int)n_nodes, conv_group(0, n_nodes));
+    }
+    TFC_LAUNCH_CHECK("tfc_conv_fwd_fused_kernel");
     return TFC_OK;
 }
 

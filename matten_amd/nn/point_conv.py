@@ -61,6 +61,7 @@ class _RadialChain(threading.local):
         self.pass_layers = []  # weakrefs of the layers of the current pass, in order
         self.next_of = weakref.WeakKeyDictionary()  # layer -> weakref of its successor
         self.prefetched = weakref.WeakKeyDictionary()  # layer -> (key, embedding, weights, event)
+        self.hub = None  # (embedding, its alias recorded under the side stream)
 
 
 _CHAIN = _RadialChain()
@@ -70,6 +71,24 @@ def _radial_key(layer, emb):
     """Everything the radial network's output depends on besides the values of `emb`."""
     return (id(emb), emb.data_ptr(), emb._version, torch.is_grad_enabled(),
             tuple((p.data_ptr(), p._version) for p in layer.tp.weight_nn.parameters()))
+
+
+def _embedding_hub(emb, side):
+    """An alias of the edge embedding whose autograd node lives on the side stream, shared by the radial
+    networks of a pass.  Every layer's network sends a gradient to the embedding; fed the tensor itself, autograd
+    sums those on the embedding's own (main) stream as they arrive, which parks the main stream behind each radial
+    network's backward in turn.  Through the alias the partial gradients meet on the side stream, and the main
+    stream waits once, for the finished sum, when the edge encoders' backward finally needs it."""
+    if not (ops.MLP_EMBEDDING_HUB and emb.requires_grad and torch.is_grad_enabled()):
+        return emb
+    hit = _CHAIN.hub
+    if hit is not None and hit[0] is emb and hit[2] == emb._version:
+        return hit[1]
+    side.wait_stream(torch.cuda.current_stream(emb.device))
+    with torch.cuda.stream(side):
+        hub = emb.view(emb.shape)
+    _CHAIN.hub = (emb, hub, emb._version)
+    return hub
 
 
 def _note_radial_chain(layer, emb_key):
@@ -118,8 +137,9 @@ class PointConvMessage(ModuleIrreps, torch.nn.Module):
         call only records the autograd node, HERE in the forward order - had the prefetching layer recorded
         it, autograd would run its backward after that earlier layer's convolution backward, at the very end
         of the pass with nothing left to overlap it with."""
+        src = _embedding_hub(emb, side)
         with torch.cuda.stream(side):
-            w = self.tp.weight_nn(emb, pre=pre)
+            w = self.tp.weight_nn(src, pre=pre)
             ready = None
             if pre is None:
                 ready = torch.cuda.Event()

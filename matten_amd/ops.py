@@ -797,6 +797,9 @@ MLP_PREFETCH_AFTER_CONV = _os_environ.get("TFC_MLP_PREFETCH_AFTER_CONV", "0") !=
 # Measured at config 3 (graph replay / eager): 3.39 / 3.53 ms against 3.50 / 3.69 - the convolution backward loses
 # more to the shared CUs than the exposed tail of two small networks costs
 MLP_PREFETCH_RECORD_EARLY = _os_environ.get("TFC_MLP_PREFETCH_RECORD_EARLY", "1") != "0"
+# the radial networks of a pass read the edge embedding through one alias recorded under the side stream, so that
+# their gradients to it are summed there and not, one by one, on the main stream (nn/point_conv.py:_embedding_hub)
+MLP_EMBEDDING_HUB = _os_environ.get("TFC_MLP_EMBEDDING_HUB", "1") != "0"
 MLP_PREFETCH_DEPTH = int(_os_environ.get("TFC_MLP_PREFETCH_DEPTH", "1"))
 _SIDE_STREAMS: "dict[int, torch.cuda.Stream]" = {}
 

@@ -906,3 +906,42 @@ def test_cell_gradient_vs_oracle(device, graphs):
         outs.append((gp, gc))
     assert outs[1][1].shape == outs[0][1].shape == (3 * graphs, 3)
     assert rel(outs[1][0], outs[0][0]) < TOL and rel(outs[1][1], outs[0][1]) < TOL
+
+
+def test_conv_fwd_with_last_mlp_layer_folded_in(device):
+    """tfc_conv_fwd_fused_m (the radial network's last layer formed inside the convolution, w never written)
+    against the fp64 oracle and against the shipped two-step route."""
+    import ctypes as C
+
+    from matten_amd import _lib, ops
+    from matten_amd.nn.utils import UVUTensorProduct
+    from oracle import eigenn_ref as R
+
+    in1, sh, out = "40x0e+24x1o+24x1e+10x2e", "0e+1o+2e", "40x0o+40x0e+24x1o+24x1e+10x2o+10x2e"
+    torch.manual_seed(4)
+    o = R.UVUTensorProduct(in1, sh, out, mlp_input_size=8, mlp_hidden_size=64, mlp_num_hidden_layers=2)
+    h = UVUTensorProduct(in1, sh, out, mlp_input_size=8, mlp_hidden_size=64, mlp_num_hidden_layers=2)
+    n_nodes, n_edges = 6, 500
+    ei = random_graph(n_nodes, n_edges, 5, "cpu")
+    x = torch.randn(n_nodes, o.tp.irreps_in1.dim, dtype=torch.float64)
+    y = R.spherical_harmonics(sh, torch.randn(n_edges, 3, dtype=torch.float64), True, "component")
+    hid = torch.randn(n_edges, 64, dtype=torch.float64)
+    w_last = torch.randn(64, o.tp.weight_numel, dtype=torch.float64)
+    ref = R.scatter_add(o.tp(x[ei[0]], y, hid @ w_last / 8.0), ei[1], n_nodes) * 0.3
+    xg, yg, hg, wg = (t.float().to(device) for t in (x, y, hid, w_last))
+    ordering = ops.EdgeOrdering(ei.to(device), n_nodes)
+    plan = h.tp.plan
+    rows = ordering.by_dst
+    M = ordering.m_matrices(plan, yg, rows)
+    got = torch.full((n_nodes, plan.d_out), float("nan"), device=device)
+    P = lambda t: C.c_void_p(t.data_ptr())  # noqa: E731
+    L = _lib.lib()
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    rc = L.tfc_conv_fwd_fused_m(plan.handle(xg.device), P(xg), P(M), P(hg), P(wg), 64, 0.125, P(rows[0]), P(rows[1]), P(rows[2]), n_nodes, n_edges,
+                                0.3, P(got), st)
+    assert rc == 0, L.tfc_last_error()
+    assert rel(got, ref) < TOL
+    shipped = h.tp(xg, yg, (hg @ wg) * 0.125, ordering, 0.3)
+    assert rel(got, shipped) < TOL
+    assert L.tfc_conv_fwd_fused_m(plan.handle(xg.device), P(xg), P(M), P(hg), P(wg), 32, 0.125, P(rows[0]), P(rows[1]), P(rows[2]), n_nodes,
+                                  n_edges, 0.3, P(got), st) == -2

@@ -14,7 +14,11 @@ dev = torch.device("cuda")
 batch = bench.build_batch(wl, 0, dev)
 torch.manual_seed(35)
 model = ConvStack(H, wl["emb"], wl["lmax"], wl["irreps"], wl["layers"], 64, 2, 5.0, 28.0).to(dev)
-params = list(model.parameters())
+if os.environ.get("NO_WGRAD"):
+    for n_, p_ in model.named_parameters():
+        if any(k in n_ for k in ("linear_1", "linear_2", "self_connection")):
+            p_.requires_grad_(False)
+params = [p for p in model.parameters() if p.requires_grad]
 bucket = FlatGradBucket(params)
 pos0 = batch[K.POSITIONS]
 
