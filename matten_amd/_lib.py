@@ -9,7 +9,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libtfc.so")
+LIB_PATH = os.environ.get("TFC_LIB_PATH") or os.path.join(_HERE, "libtfc.so")  # (TFC_LIB_PATH: kernel experiments, tools/build_variant.sh)
 
 
 class TfcError(RuntimeError):

@@ -137,7 +137,13 @@ __device__ __forceinline__ void fwd_item(const float* __restrict__ x, const floa
                                          int u, bool active, int node, int d_in, int d_out, int w_numel,
                                          int msz, float scale, float* __restrict__ out) {
     constexpr int D1 = 2 * L1 + 1, D3 = 2 * L3 + 1;
-    constexpr int UNR = D1 <= 3 ? 8 : 4;
+    // edges in flight per step: 4 / 2 (was 8 / 4: the M blocks of that many edges need more scalar registers than
+    // there are, and the compiler spills them through v_writelane; config-3 last layer 174 -> 161 us)
+#ifndef TFC_FWD_UNR_A
+#define TFC_FWD_UNR_A 4
+#define TFC_FWD_UNR_B 2
+#endif
+    constexpr int UNR = D1 <= 3 ? TFC_FWD_UNR_A : TFC_FWD_UNR_B;
     const int lane = threadIdx.x & 63;
     const int uu = active ? u : 0;  // idle lanes shadow channel 0: valid addresses, nothing stored
     const float* xb = x + p.x_off + uu * D1;
