@@ -194,21 +194,19 @@ int tfc_conv_bwd(const tfc_conv_plan* plan, const float* x, const float* y, cons
                  float* workspace, tfc_stream_t stream);
 
 /* The same two calls with the per-edge matrices M_e[m1][m3] = sum_m2 C[m1][m2][m3] y[e][m2] (what
- * the kernels actually read, in the order of `eid`) built by the caller beforehand.  M depends on
- * the edge attributes, the ordering and the set of (l1, l2, l3) blocks of the plan only, so the
- * layers of a model that share all three (every PointConvMessagePassing after the first, whose
- * e3nn TensorProducts use the same Clebsch-Gordan blocks, eigenn/nn/utils.py:205-229) can share one
- * M per ordering instead of rebuilding it in every forward and backward call.
+ * the kernels actually read; rows in the caller's EDGE order, looked up by edge id) built by the caller
+ * beforehand.  M depends on the edge attributes and the set of (l1, l2, l3) blocks of the plan only, so
+ * the layers of a model that share both (every PointConvMessagePassing after the first, whose
+ * e3nn TensorProducts use the same Clebsch-Gordan blocks, eigenn/nn/utils.py:205-229) share ONE M,
+ * forward and backward, instead of rebuilding it in every call.
  *   tfc_conv_m_signature : equal for two plans <=> their M rows have the same layout
  *   tfc_conv_m_floats    : size of M for E edges;  tfc_conv_dy_floats: size of `dyp` (backward scratch
  *                          for the partial edge-attribute gradients, needed when dy is non-null)
- *   tfc_conv_m_build     : M from y [E, d_sh] and eid [E] (receiver ordering for forward, sender
- *                          ordering for backward) */
+ *   tfc_conv_m_build     : M from y [E, d_sh] */
 int64_t tfc_conv_m_signature(const tfc_conv_plan* plan);
 int64_t tfc_conv_m_floats(const tfc_conv_plan* plan, int64_t n_edges);
 int64_t tfc_conv_dy_floats(const tfc_conv_plan* plan, int64_t n_edges);
-int tfc_conv_m_build(const tfc_conv_plan* plan, const float* y, const int32_t* eid, int64_t n_edges, float* M,
-                     tfc_stream_t stream);
+int tfc_conv_m_build(const tfc_conv_plan* plan, const float* y, int64_t n_edges, float* M, tfc_stream_t stream);
 int tfc_conv_fwd_m(const tfc_conv_plan* plan, const float* x, const float* M, const float* w,
                    const int32_t* row_ptr, const int32_t* eid, const int32_t* nbr, int64_t n_nodes,
                    int64_t n_edges, float scale, float* out, tfc_stream_t stream);

@@ -128,7 +128,7 @@ SIGNATURES = {
     "tfc_conv_m_signature": (_I64, [_P]),
     "tfc_conv_m_floats": (_I64, [_P, _I64]),
     "tfc_conv_dy_floats": (_I64, [_P, _I64]),
-    "tfc_conv_m_build": (C.c_int, [_P, _P, _P, _I64, _P, _P]),
+    "tfc_conv_m_build": (C.c_int, [_P, _P, _I64, _P, _P]),
     "tfc_conv_fwd_m": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _I64, _I64, _F, _P, _P]),
     "tfc_conv_fwd_fused_m": (C.c_int, [_P, _P, _P, _P, _P, _I32, _F, _P, _P, _P, _I64, _I64, _F, _P, _P]),
     "tfc_conv_bwd_m": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _I64, _I64, _F, _P, _P, _P, _P, _P]),

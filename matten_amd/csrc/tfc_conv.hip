@@ -76,10 +76,10 @@ struct tfc_conv_plan {
 };
 
 // ------------------------------------------------------------------------------------------
-// M pre-pass: M[k][j] for sorted position k and M-row entry j.
+// M pre-pass: M[e][j] for edge e (the caller's edge order) and M-row entry j.  One M serves the forward (edges
+// grouped by receiver) and the backward (grouped by sender): both kernels look a row up by edge id.
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void tfc_m_prepass_kernel(const float* __restrict__ y,
-                                                            const int* __restrict__ eid,
                                                             const MEnt* __restrict__ ments,
                                                             const float* __restrict__ cgm, long n_edges,
                                                             int msz, int d_sh, float* __restrict__ M) {
@@ -89,7 +89,7 @@ __global__ __launch_bounds__(256) void tfc_m_prepass_kernel(const float* __restr
         const long k = i / msz;
         const int j = (int)(i - k * msz);
         const MEnt me = ments[j];
-        const float* yr = y + (long)eid[k] * d_sh + me.y_off;
+        const float* yr = y + k * d_sh + me.y_off;
         float v = 0.f;
         for (int m2 = 0; m2 < me.n2; ++m2) v = fmaf(cgm[me.cg_row + m2], yr[m2], v);
         M[i] = v;
@@ -119,7 +119,7 @@ __device__ __forceinline__ void fwd_edges(const float* __restrict__ xb, const fl
     }
 #pragma unroll
     for (int j = 0; j < UNR; ++j) {
-        const float* Mk = Mb + (size_t)(k + j) * msz;
+        const float* Mk = Mb + (size_t)__builtin_amdgcn_readlane(ev, j0 + j) * msz;  // M rows are in edge order
 #pragma unroll
         for (int m3 = 0; m3 < D3; ++m3) {
             float z = 0.f;
@@ -255,7 +255,7 @@ __device__ __forceinline__ void fwdw_edges(const float* __restrict__ xb, const f
     }
 #pragma unroll
     for (int j = 0; j < UNR; ++j) {
-        const float* Mk = Mb + (size_t)(k + j) * msz;
+        const float* Mk = Mb + (size_t)__builtin_amdgcn_readlane(ev, j0 + j) * msz;
 #pragma unroll
         for (int m3 = 0; m3 < D3; ++m3) {
             float z = 0.f;
@@ -345,7 +345,13 @@ __global__ __launch_bounds__(256) void tfc_conv_fwd_fused_kernel(
 // at a time by the reduce-scatter butterfly of tfc_common.h instead of one at a time.
 template <int D2>
 struct BwdUnroll {
-    static constexpr int U = D2 == 1 ? 4 : (D2 == 3 ? 5 : (D2 == 5 ? 3 : 2));  // U * D2 <= 16
+#ifndef TFC_BWD_U1
+#define TFC_BWD_U1 4
+#define TFC_BWD_U3 5
+#define TFC_BWD_U5 3
+#define TFC_BWD_U7 2
+#endif
+    static constexpr int U = D2 == 1 ? TFC_BWD_U1 : (D2 == 3 ? TFC_BWD_U3 : (D2 == 5 ? TFC_BWD_U5 : TFC_BWD_U7));  // U * D2 <= 16
     static constexpr int V = D2 == 1 ? 4 : 16;
 };
 
@@ -407,8 +413,7 @@ __device__ __forceinline__ void bwd_path(const float* __restrict__ w, const floa
 #pragma unroll
         for (int j = 0; j < U; ++j) {
             const bool ok = k + j < end;
-            const int kk = ok ? k + j : end - 1;
-            const float* Mk = Mb + (size_t)kk * msz;
+            const float* Mk = Mb + (size_t)e[j] * msz;  // M rows are in edge order
             const float wj = ok ? wv[j] : 0.f;
 #pragma unroll
             for (int m3 = 0; m3 < D3; ++m3) g[j][m3] *= cs;
@@ -786,16 +791,16 @@ extern "C" int64_t tfc_conv_m_floats(const tfc_conv_plan* plan, int64_t n_edges)
     return f > 0 ? f : 1;
 }
 
-extern "C" int tfc_conv_m_build(const tfc_conv_plan* pl, const float* y, const int32_t* eid, int64_t n_edges,
-                                float* M, tfc_stream_t stream_) {
+extern "C" int tfc_conv_m_build(const tfc_conv_plan* pl, const float* y, int64_t n_edges, float* M,
+                                tfc_stream_t stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     TFC_REQUIRE(pl, TFC_EINVAL, "tfc_conv_m_build: null plan");
     TFC_REQUIRE(n_edges >= 0 && n_edges < (1LL << 31), TFC_EINVAL, "tfc_conv_m_build: bad edge count");
     if (n_edges == 0) return TFC_OK;
-    TFC_REQUIRE(y && eid && M, TFC_EINVAL, "tfc_conv_m_build: null tensor");
+    TFC_REQUIRE(y && M, TFC_EINVAL, "tfc_conv_m_build: null tensor");
     TfcProfScope prof("tfc_m_prepass_kernel", stream);
     tfc_m_prepass_kernel<<<grid_for(n_edges * (long)pl->msz, 256), 256, 0, stream>>>(
-        y, eid, pl->ments, pl->cgm, (long)n_edges, pl->msz, pl->d_sh, M);
+        y, pl->ments, pl->cgm, (long)n_edges, pl->msz, pl->d_sh, M);
     TFC_LAUNCH_CHECK("tfc_m_prepass_kernel");
     return TFC_OK;
 }
@@ -881,7 +886,7 @@ extern "C" int tfc_conv_fwd(const tfc_conv_plan* pl, const float* x, const float
     TFC_REQUIRE(pl, TFC_EINVAL, "tfc_conv_fwd: null plan");
     TFC_REQUIRE(n_edges <= 0 || n_nodes <= 0 || (y && eid && workspace), TFC_EINVAL, "tfc_conv_fwd: null tensor");
     if (n_nodes > 0 && n_edges > 0) {
-        const int rc = tfc_conv_m_build(pl, y, eid, n_edges, workspace, stream);
+        const int rc = tfc_conv_m_build(pl, y, n_edges, workspace, stream);
         if (rc) return rc;
     }
     return tfc_conv_fwd_m(pl, x, workspace, w, row_ptr, eid, nbr, n_nodes, n_edges, scale, out, stream);
@@ -944,7 +949,7 @@ extern "C" int tfc_conv_bwd(const tfc_conv_plan* pl, const float* x, const float
     TFC_REQUIRE(pl, TFC_EINVAL, "tfc_conv_bwd: null plan");
     TFC_REQUIRE(n_edges <= 0 || n_nodes <= 0 || (y && eid && workspace), TFC_EINVAL, "tfc_conv_bwd: null tensor");
     if (n_nodes > 0 && n_edges > 0) {
-        const int rc = tfc_conv_m_build(pl, y, eid, n_edges, workspace, stream);
+        const int rc = tfc_conv_m_build(pl, y, n_edges, workspace, stream);
         if (rc) return rc;
     }
     float* dyp = workspace ? workspace + (size_t)(n_edges > 0 ? n_edges : 0) * pl->msz : nullptr;

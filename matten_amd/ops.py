@@ -144,18 +144,18 @@ class EdgeOrdering:
         return self
 
     def m_matrices(self, plan: "ConvPlan", y: torch.Tensor, rows) -> torch.Tensor:
-        """The per-edge matrices M_e (CG tensor contracted with the edge attributes) in the order of
-        `rows`, built once and shared by every layer whose plan lays M out the same way (and that
+        """The per-edge matrices M_e (CG tensor contracted with the edge attributes), rows in edge order, built
+        once and shared - forward and backward - by every layer whose plan lays M out the same way (and that
         sees the same edge-attribute tensor): tfc_conv_m_build."""
         L = _lib.lib()
         h = plan.handle(y.device)
-        key = (int(L.tfc_conv_m_signature(h)), rows[1].data_ptr(), y.data_ptr(), y._version)
+        key = (int(L.tfc_conv_m_signature(h)), y.data_ptr(), y._version)
         hit = self._m_cache.get(key)
         if hit is not None:
             return hit[0]
         E = y.shape[0]
         M = torch.empty(int(L.tfc_conv_m_floats(h, E)), dtype=torch.float32, device=y.device)
-        _lib.check(L.tfc_conv_m_build(h, _ptr(y), _ptr(rows[1]), E, _ptr(M), _stream()))
+        _lib.check(L.tfc_conv_m_build(h, _ptr(y), E, _ptr(M), _stream()))
         if len(self._m_cache) >= 4:
             self._m_cache.pop(next(iter(self._m_cache)))
         self._m_cache[key] = (M, y)  # holding y keeps its address from being reused while cached
