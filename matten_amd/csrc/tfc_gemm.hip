@@ -323,14 +323,27 @@ __global__ __launch_bounds__(256, (TM * TN == 4 ? 4 : 1)) void tfc_gemm_kernel(c
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    Operand<BM, A_KFAST, HAS2, AV, REP> A;
-    Operand<BN, B_KFAST, false, BV, 1> B;
+    // Two tiles of operands are in flight in registers: while tile i is multiplied, tile i + 1 (requested one
+    // iteration ago) is moved to LDS and tile i + 2 is requested - a load has two iterations to arrive instead of
+    // one (the MFMAs of one 16-deep tile last ~0.2 us, a load from L2 / HBM several times that).  The loop is
+    // unrolled by two so that the two register sets keep fixed names.
+    Operand<BM, A_KFAST, HAS2, AV, REP> A0, A1;
+    Operand<BN, B_KFAST, false, BV, 1> B0, B1;
     const long rs1 = P.a1_rs, rs2 = P.a2_rs;
+    auto request = [&](auto& A, auto& B, int tile) {  // tile: relative index
+        const int kb_ = (tile / KT) & 1, ko_ = (tile % KT) * BK;
+        A.load(pa1, pa2, roffA, roffA2, koff[kb_][0] + ko_, koff[kb_][1] + ko_, t, rs1, rs2);
+        B.load(pb, nullptr, roffB, nullptr, koff[kb_][2] + ko_, nullptr, t, 0, 0);
+    };
+    auto stage = [&](const auto& A, const auto& B, int tile) {
+        const int k_left = K - (kt_begin + tile) * BK;
+        A.store(tiles + (tile & 1) * TILE, t, k_left);
+        B.store(tiles + (tile & 1) * TILE + BK * SA, t, k_left);
+    };
     if (n_tiles > 0) {
-        A.load(pa1, pa2, roffA, roffA2, koff[0][0], koff[0][1], t, rs1, rs2);
-        B.load(pb, nullptr, roffB, nullptr, koff[0][2], nullptr, t, 0, 0);
-        A.store(tiles, t, K - kt_begin * BK);
-        B.store(tiles + BK * SA, t, K - kt_begin * BK);
+        request(A0, B0, 0);
+        if (n_tiles > 1) request(A1, B1, 1);
+        stage(A0, B0, 0);
     }
     __syncthreads();
 
@@ -352,25 +365,23 @@ __global__ __launch_bounds__(256, (TM * TN == 4 ? 4 : 1)) void tfc_gemm_kernel(c
                     acc[ii][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[ii], bf[j], acc[ii][j], 0, 0, 0);
         }
     };
-    // steady state: tile i + 1 is loaded and staged unconditionally (the last tile is peeled off, so
-    // that the staging registers are not live under a condition across the MFMA block)
-    for (int i = 0; i + 1 < n_tiles; ++i) {
-        const int cur = i & 1, nxt = cur ^ 1;
-        {
-            const int kb_ = ((i + 1) / KT) & 1, ko_ = ((i + 1) % KT) * BK;
-            A.load(pa1, pa2, roffA, roffA2, koff[kb_][0] + ko_, koff[kb_][1] + ko_, t, rs1, rs2);
-            B.load(pb, nullptr, roffB, nullptr, koff[kb_][2] + ko_, nullptr, t, 0, 0);
-        }
-        mfma_tile(cur);
-        // the offsets of tiles i + KT .. replace those of tiles i - KT .. i - 1 (last read before
-        // the previous barrier); they are first read in iteration i + KT - 1
+    // iteration i: request tile i + 2 into the set that held tile i (already in LDS), multiply tile i, move tile
+    // i + 1 to LDS.  The k offsets of tiles i + KT .. replace those of tiles i - KT .. i - 1 when i is a multiple of
+    // KT; the request of tile i + 2 reads the table filled at least KT - 2 iterations (and one barrier) earlier.
+    auto iteration = [&](auto& Aold, auto& Bold, const auto& Anext, const auto& Bnext, int i) {
+        if (i + 2 < n_tiles) request(Aold, Bold, i + 2);
+        mfma_tile(i & 1);
         if (i % KT == 0 && i + KT < n_tiles) fill_koff(i + KT);
-        {
-            const int k_left = K - (kt_begin + i + 1) * BK;
-            A.store(tiles + nxt * TILE, t, k_left);
-            B.store(tiles + nxt * TILE + BK * SA, t, k_left);
-        }
+        stage(Anext, Bnext, i + 1);
         __syncthreads();
+    };
+    {
+        int i = 0;
+        for (; i + 2 < n_tiles; i += 2) {
+            iteration(A0, B0, A1, B1, i);
+            iteration(A1, B1, A0, B0, i + 1);
+        }
+        if (i + 1 < n_tiles) iteration(A0, B0, A1, B1, i);
     }
     if (n_tiles > 0) mfma_tile((n_tiles - 1) & 1);
 
