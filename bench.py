@@ -258,10 +258,10 @@ def main():
         b[K.POSITIONS] = pos
         _, energy, _ = model(b, wl["graphs"])
         energy.sum().backward()
-        return pos.grad  # = -forces
+        return pos.grad, [p.grad for p in params]  # (-forces, parameter gradients)
 
     def eager_step():
-        g = compute()
+        g, _ = compute()
         if _SYNC_BEFORE_AR:
             torch.cuda.synchronize()
         bucket.all_reduce_mean()
@@ -282,8 +282,8 @@ def main():
             mode = "hip_graph_replay"
 
             def step():
-                g = replay()
-                bucket.all_reduce_mean()
+                g, grads = replay()  # the tensors the captured step writes its gradients into
+                bucket.all_reduce_mean(grads=grads)
                 return g
 
     def sync():

@@ -60,6 +60,7 @@ struct tfc_conv_plan {
     int msz;  // floats per edge of the M buffer (multiple of 4)
     int py;   // floats per edge of the partial-dy buffer
     int n_fwd_items, n_bwd_items;
+    int dx_covered;  // every column of an input row belongs to an in1 block some path reads (dx needs no zero fill)
     int lmax;  // largest l1, l2 or l3 of any path
     long m_sig;  // hash of the layout of an M row (the list of (l1, l2, l3, y_off) blocks)
     int device;
@@ -740,6 +741,13 @@ extern "C" int tfc_conv_plan_create(const tfc_path* paths, int32_t n_paths, int3
     pl->py = py;
     pl->n_fwd_items = (int)fwd_items.size();
     pl->n_bwd_items = (int)bwd_items.size();
+    {
+        std::vector<char> used(d_in, 0);
+        for (int i = 0; i < n_paths; ++i)
+            for (int c = pd[i].x_off; c < pd[i].x_off + pd[i].mul * (2 * pd[i].l1 + 1); ++c) used[c] = 1;
+        pl->dx_covered = 1;
+        for (int c = 0; c < d_in; ++c) pl->dx_covered &= used[c];
+    }
     pl->m_sig = 1469598103934665603L;
     for (auto& t : triples) {
         int v[4];
@@ -911,10 +919,13 @@ extern "C" int tfc_conv_bwd_m(const tfc_conv_plan* pl, const float* x, const flo
     TFC_REQUIRE(x && gout && dx && row_ptr, TFC_EINVAL, "tfc_conv_bwd: null tensor");
     TFC_REQUIRE(n_edges == 0 || (M && w && dw && eid && nbr && (!dy || dyp)), TFC_EINVAL,
                 "tfc_conv_bwd: null tensor");
-    // columns of dx / dw that no path touches must still be defined
-    tfc_fill_kernel<<<grid_for((long)n_nodes * pl->d_in, 256, 2048), 256, 0, stream>>>(
-        dx, (long)n_nodes * pl->d_in, 0.f);
-    TFC_LAUNCH_CHECK("tfc_fill_kernel");
+    // columns of dx that no path reads must still be defined (none in the layers the reference builds: every
+    // block of the sorted, simplified input irreps has a path with the scalar spherical harmonic)
+    if (!pl->dx_covered) {
+        tfc_fill_kernel<<<grid_for((long)n_nodes * pl->d_in, 256, 2048), 256, 0, stream>>>(
+            dx, (long)n_nodes * pl->d_in, 0.f);
+        TFC_LAUNCH_CHECK("tfc_fill_kernel");
+    }
     const long n_tasks = (long)n_nodes * pl->n_bwd_items;
     const long n_blocks = (n_tasks + 3) / 4;
     TFC_REQUIRE(n_blocks < (1LL << 31), TFC_EUNSUPPORTED, "tfc_conv_bwd: grid too large");

@@ -43,7 +43,7 @@ class FlatGradBucket:
     only the last, smallest one (the first layer's) is exposed after backward ends."""
 
     def __init__(self, params: Iterable[torch.nn.Parameter], bucket_bytes: int = 8 << 20, overlap: bool = False, group=None,
-                 force: bool = False):
+                 force: bool = False, alias: "bool | None" = None):
         self.params = [p for p in params if p.requires_grad]
         if not self.params:
             raise ValueError("no trainable parameters")
@@ -54,6 +54,14 @@ class FlatGradBucket:
         self.flat = torch.zeros(sum(p.numel() for p in self.params), dtype=dt, device=dev)
         self.group = group
         self.overlap = overlap
+        # alias=True: every p.grad is a view into `flat` for the whole run (needed to reduce slices while backward is
+        # still running).  alias=False (default without overlap): gradients are left to autograd - zero() drops them,
+        # so backward hands each parameter its gradient tensor as is instead of launching one `grad += new` kernel
+        # per parameter into a zeroed buffer - and all_reduce_mean() packs them into `flat` with one concatenation
+        # right before the collective, after which the parameters' .grad are views of the reduced buffer.
+        self.alias = bool(overlap) if alias is None else bool(alias)
+        if overlap and not self.alias:
+            raise ValueError("overlap=True needs alias=True")
         self.force = force  # run the collectives even in a group of one rank (exercises the RCCL path on one GPU)
         self._views = {}  # id(param) -> (offset, numel): where its gradient lives in `flat`
         self.bounds: List[Tuple[int, int]] = []  # [begin, end) of each slice in `flat`
@@ -62,7 +70,8 @@ class FlatGradBucket:
         off = begin = count = 0
         item = self.flat.element_size()
         for p in reversed(self.params):
-            p.grad = self.flat[off : off + p.numel()].view_as(p)
+            if self.alias:
+                p.grad = self.flat[off : off + p.numel()].view_as(p)
             self._views[id(p)] = (off, p.numel())
             self._slice_of[id(p)] = len(self.bounds)
             off += p.numel()
@@ -109,23 +118,54 @@ class FlatGradBucket:
     def zero(self):
         """Start of a step: clears the gradients and re-arms the slices.  Gradients that no longer alias the
         buffer (optimizer.zero_grad() sets them to None by default) are pointed back into it."""
-        self.flat.zero_()
-        for p in self.params:
-            if not self._aliased(p):
-                off, n = self._views[id(p)]
-                p.grad = self.flat[off : off + n].view_as(p)
+        if not self.alias:
+            for p in self.params:
+                p.grad = None
+        else:
+            self.flat.zero_()
+            for p in self.params:
+                if not self._aliased(p):
+                    off, n = self._views[id(p)]
+                    p.grad = self.flat[off : off + n].view_as(p)
         self._pending = list(self._n_in_slice)
         self._works = [None] * len(self.bounds)
         self._next = 0
 
-    def all_reduce_mean(self, group=None):
-        """End of backward: every gradient becomes the mean over the ranks."""
+    def all_reduce_mean(self, group=None, grads: "Sequence[torch.Tensor] | None" = None):
+        """End of backward: every gradient becomes the mean over the ranks.  `grads` (alias=False only): the
+        gradient tensors to reduce, in the order of the parameters, when they are not the parameters' current
+        `.grad` - a step replayed from a HIP graph writes into the tensors that were `.grad` when it was captured,
+        whatever `.grad` points to now."""
         if group is not None:
             self.group = group
         if not self._active():
             return
         import torch.distributed as dist
 
+        if not self.alias:
+            # pack (one kernel), reduce, and leave every .grad a view of the reduced buffer
+            order = list(reversed(self.params))
+            if grads is not None:
+                if len(grads) != len(self.params):
+                    raise ValueError("all_reduce_mean: one gradient per parameter expected")
+                src = {id(p): g for p, g in zip(self.params, grads)}
+            else:
+                src = {id(p): p.grad for p in self.params}
+            parts = []
+            for p in order:
+                g = src[id(p)]
+                if g is not None and g.data_ptr() == self.flat.data_ptr() + self._views[id(p)][0] * self.flat.element_size():
+                    raise RuntimeError("FlatGradBucket: a gradient already lives in the flat buffer (all_reduce_mean called "
+                                       "twice without a backward in between, or a replayed step without `grads=`)")
+                parts.append((g if g is not None else torch.zeros_like(p)).reshape(-1))
+            torch.cat(parts, out=self.flat)
+            work = dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+            work.wait()
+            self.flat.div_(dist.get_world_size(self.group))
+            for p in order:
+                off, n = self._views[id(p)]
+                p.grad = self.flat[off : off + n].view_as(p)
+            return
         for p in self.params:
             if not self._aliased(p):
                 # e.g. optimizer.zero_grad(set_to_none=True) after zero(): backward then wrote to a fresh tensor

@@ -53,7 +53,7 @@ def test_shard_graphs_partition():
 
 def test_flat_bucket_aliases_grads():
     model = _model()
-    b = FlatGradBucket(model.parameters())
+    b = FlatGradBucket(model.parameters(), alias=True)
     x, y = _data()
     _loss(model, x, y, list(range(8))).backward()
     off = 0
@@ -90,7 +90,7 @@ def test_flat_bucket_survives_zero_grad_and_refuses_stale_buffers():
     dist.init_process_group("gloo", rank=0, world_size=1)
     try:
         model = _model()
-        b = FlatGradBucket(model.parameters(), force=True)  # force: run the collective in a group of one
+        b = FlatGradBucket(model.parameters(), force=True, alias=True)  # force: run the collective in a group of one
         opt = torch.optim.SGD(model.parameters(), lr=0.1)
         x, y = _data()
         b.zero()
@@ -106,6 +106,15 @@ def test_flat_bucket_survives_zero_grad_and_refuses_stale_buffers():
         _loss(model, x, y, list(range(8))).backward()  # fresh .grad tensors, the buffer is stale
         with pytest.raises(RuntimeError, match="no longer aliases"):
             b.all_reduce_mean()
+        # the default (alias=False): gradients stay autograd's own until the collective packs them
+        model2 = _model()
+        b2 = FlatGradBucket(model2.parameters(), force=True)
+        for _ in range(2):
+            b2.zero()
+            assert all(p.grad is None for p in model2.parameters())
+            _loss(model2, x, y, list(range(8))).backward()
+            b2.all_reduce_mean()
+            assert torch.equal(b2.flat, ref) and all(b2._aliased(p) for p in model2.parameters())
     finally:
         dist.destroy_process_group()
 
