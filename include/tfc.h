@@ -215,6 +215,25 @@ int tfc_conv_bwd_m(const tfc_conv_plan* plan, const float* x, const float* M, co
                    int64_t n_edges, float scale, float* dx, float* dw, float* dy, float* dyp,
                    tfc_stream_t stream);
 
+/* The same two calls writing a SECOND, channel-contiguous copy of their node-row result (the layout
+ * tfc_ir_transpose produces, which tfc_linear_fwd / tfc_linear_bwd consume), so that the o3.Linear that follows
+ * the convolution (linear_2, eigenn/nn/point_conv.py:130-135) or precedes it (linear_1, :56-61, in the backward)
+ * needs no transposing pass of its own.  No counterpart in the reference (layout plumbing between two kernels).
+ *   out_t [d_out * N]: block b = (off, mul, dim) of the output row, as given to tfc_conv_plan_set_out_blocks
+ *                      (every path's output must lie inside one block of its own 2l3+1), is written at
+ *                      out_t[off * N + (m * N + n) * mul + channel]; may be null
+ *   dx_t  [d_in * N] : the in1 blocks (x_off, mul, 2l1+1) of the paths in the same layout; columns no path
+ *                      reads are left untouched; may be null */
+struct tfc_ir_block; /* (off, mul, dim), defined with tfc_ir_transpose below */
+int tfc_conv_plan_set_out_blocks(tfc_conv_plan* plan, const struct tfc_ir_block* blocks, int32_t n_blocks);
+int tfc_conv_fwd_m_t(const tfc_conv_plan* plan, const float* x, const float* M, const float* w,
+                     const int32_t* row_ptr, const int32_t* eid, const int32_t* nbr, int64_t n_nodes,
+                     int64_t n_edges, float scale, float* out, float* out_t, tfc_stream_t stream);
+int tfc_conv_bwd_m_t(const tfc_conv_plan* plan, const float* x, const float* M, const float* w, const float* gout,
+                     const int32_t* row_ptr, const int32_t* eid, const int32_t* nbr, int64_t n_nodes,
+                     int64_t n_edges, float scale, float* dx, float* dx_t, float* dw, float* dy, float* dyp,
+                     tfc_stream_t stream);
+
 /* tfc_conv_fwd_m with the LAST layer of the radial network folded in (eigenn/nn/utils.py:262 is where the
  * weights are born, :265 where they are consumed): the per-edge weights are never materialised,
  *     w[e, j] = alpha * sum_k h[e, k] * w_last[k, j],   h [E, hidden] the last hidden activations,
@@ -390,6 +409,11 @@ typedef struct tfc_linear_ins {
 int64_t tfc_linear_workspace_floats(const tfc_linear_ins* ins, int32_t n_ins, int64_t n_rows);
 int tfc_linear_fwd(const tfc_linear_ins* ins, int32_t n_ins, const float* x, const float* weight, int64_t n_rows,
                    int32_t d_in, int32_t d_out, int64_t weight_numel, float* xt, float* out, tfc_stream_t stream);
+/* the same with xt_ready != 0: `xt` already holds the channel-contiguous copy (e.g. written by
+ * tfc_conv_fwd_m_t) and x is not read */
+int tfc_linear_fwd_t(const tfc_linear_ins* ins, int32_t n_ins, const float* x, const float* weight, int64_t n_rows,
+                     int32_t d_in, int32_t d_out, int64_t weight_numel, float* xt, int32_t xt_ready, float* out,
+                     tfc_stream_t stream);
 int tfc_linear_bwd(const tfc_linear_ins* ins, int32_t n_ins, const float* xt, const float* gout,
                    const float* weight, int64_t n_rows, int32_t d_in, int32_t d_out, int64_t weight_numel,
                    float* gt, int32_t gt_ready, float* dx, float* dw, float* workspace, int64_t workspace_floats,

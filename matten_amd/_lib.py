@@ -132,6 +132,9 @@ SIGNATURES = {
     "tfc_conv_fwd_m": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _I64, _I64, _F, _P, _P]),
     "tfc_conv_fwd_fused_m": (C.c_int, [_P, _P, _P, _P, _P, _I32, _F, _P, _P, _P, _I64, _I64, _F, _P, _P]),
     "tfc_conv_bwd_m": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _I64, _I64, _F, _P, _P, _P, _P, _P]),
+    "tfc_conv_plan_set_out_blocks": (C.c_int, [_P, C.POINTER(IrBlock), _I32]),
+    "tfc_conv_fwd_m_t": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _I64, _I64, _F, _P, _P, _P]),
+    "tfc_conv_bwd_m_t": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _I64, _I64, _F, _P, _P, _P, _P, _P, _P]),
     "tfc_edge_encode_fwd": (C.c_int, [_P, _P, _P, _P, _P, _I64, _I64, _I64, _I32, _I32, _P, _I32, _F, _F, _P, _P, _P, _P, _P]),
     "tfc_edge_bwd_blocks": (_I64, [_I64]),
     "tfc_edge_encode_bwd": (C.c_int, [_P, _P, _I64, _I32, _I32, _P, _I32, _F, _F, _P, _P, _P, _P, _P, _P, _P]),
@@ -148,6 +151,7 @@ SIGNATURES = {
                                      C.POINTER(_P), _P, _I64, _P]),
     "tfc_linear_workspace_floats": (_I64, [C.POINTER(LinearIns), _I32, _I64]),
     "tfc_linear_fwd": (C.c_int, [C.POINTER(LinearIns), _I32, _P, _P, _I64, _I32, _I32, _I64, _P, _P, _P]),
+    "tfc_linear_fwd_t": (C.c_int, [C.POINTER(LinearIns), _I32, _P, _P, _I64, _I32, _I32, _I64, _P, _I32, _P, _P]),
     "tfc_linear_bwd": (C.c_int, [C.POINTER(LinearIns), _I32, _P, _P, _P, _I64, _I32, _I32, _I64, _P, _I32, _P, _P, _P, _I64, _P]),
     "tfc_fctp_workspace_floats": (_I64, [C.POINTER(FctpIns), _I32, _I64]),
     "tfc_fctp_fwd": (C.c_int, [C.POINTER(FctpIns), _I32, _P, _P, _P, _I64, _I32, _I32, _I32, _I64, _I32, _P, _P, _I64, _P]),

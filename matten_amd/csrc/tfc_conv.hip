@@ -74,6 +74,8 @@ struct tfc_conv_plan {
     int* ylist_ptr;  // [d_sh + 1]
     int* ylist;      // partial-dy columns contributing to each edge-attribute column
     void* blob;
+    int* tout;  // [n_paths][3] (block off, block mul, first channel) of each path's output in the
+                // channel-contiguous copy (tfc_conv_plan_set_out_blocks), or null
 };
 
 // ------------------------------------------------------------------------------------------
@@ -136,7 +138,8 @@ __device__ __forceinline__ void fwd_item(const float* __restrict__ x, const floa
                                          const float* __restrict__ M, const int* __restrict__ eid,
                                          const int* __restrict__ nbr, int beg, int end, const PathDev p,
                                          int u, bool active, int node, int d_in, int d_out, int w_numel,
-                                         int msz, float scale, float* __restrict__ out) {
+                                         int msz, float scale, float* __restrict__ out,
+                                         const int* __restrict__ tout, float* __restrict__ out_t, int n_nodes) {
     constexpr int D1 = 2 * L1 + 1, D3 = 2 * L3 + 1;
     // edges in flight per step: 4 / 2 (was 8 / 4: the M blocks of that many edges need more scalar registers than
     // there are, and the compiler spills them through v_writelane; config-3 last layer 174 -> 161 us)
@@ -166,6 +169,13 @@ __device__ __forceinline__ void fwd_item(const float* __restrict__ x, const floa
         float* o = out + (size_t)node * d_out + p.out_off + u * D3;
 #pragma unroll
         for (int m3 = 0; m3 < D3; ++m3) o[m3] = cs * acc[m3];
+        if (out_t) {  // second copy, channel-contiguous: block [2l3+1][n_nodes][block mul] (256 B per wave and plane)
+            const int t_off = tout[0], t_mul = tout[1], t_ch = tout[2];
+            float* ot = out_t + (size_t)t_off * n_nodes + (size_t)node * t_mul + t_ch + u;
+            const size_t plane = (size_t)n_nodes * t_mul;
+#pragma unroll
+            for (int m3 = 0; m3 < D3; ++m3) ot[m3 * plane] = cs * acc[m3];
+        }
     }
 }
 
@@ -188,7 +198,8 @@ __global__ __launch_bounds__(256) void tfc_conv_fwd_kernel(
     const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ M,
     const int* __restrict__ row_ptr, const int* __restrict__ eid, const int* __restrict__ nbr,
     const PathDev* __restrict__ paths, const FwdItem* __restrict__ items, int n_items, long n_tasks,
-    int d_in, int d_out, int w_numel, int msz, float scale, float* __restrict__ out, int n_nodes, int group) {
+    int d_in, int d_out, int w_numel, int msz, float scale, float* __restrict__ out, int n_nodes, int group,
+    const int* __restrict__ tout, float* __restrict__ out_t) {
     const unsigned vb = tfc_xcd_remap(blockIdx.x, gridDim.x);
     const int wave = tfc_uniform((int)(threadIdx.x >> 6));
     const int lane = threadIdx.x & 63;
@@ -204,11 +215,12 @@ __global__ __launch_bounds__(256) void tfc_conv_fwd_kernel(
     const bool active = u < p.mul;
     const int beg = tfc_uniform(row_ptr[node]);
     const int end = tfc_uniform(row_ptr[node + 1]);
+    const int* tp = tout + 3 * it.path;  // read after the edge loop only
 
 #define TFC_FWD_CASE(A, B)                                                                          \
     case (A)*4 + (B):                                                                               \
         fwd_item<A, B>(x, w, M, eid, nbr, beg, end, p, u, active, node, d_in, d_out, w_numel, msz, \
-                       scale, out);                                                                 \
+                       scale, out, tp, out_t, n_nodes);                                             \
         break;
     switch (p.l1 * 4 + p.l3) {
         TFC_FWD_CASE(0, 0) TFC_FWD_CASE(0, 1) TFC_FWD_CASE(0, 2) TFC_FWD_CASE(0, 3)
@@ -463,7 +475,8 @@ __device__ __forceinline__ void bwd_item(const float* __restrict__ x, const floa
                                          const int* __restrict__ grp_paths, const BwdItem it, int beg,
                                          int end, int node, int lane, int d_in, int d_out, int w_numel,
                                          int msz, int py, float scale, float* __restrict__ dx,
-                                         float* __restrict__ dw, float* __restrict__ dyp) {
+                                         float* __restrict__ dw, float* __restrict__ dyp,
+                                         float* __restrict__ dx_t, int n_nodes) {
     constexpr int D1 = 2 * L1 + 1;
     const int u = it.chunk * 64 + lane;
     const bool active = u < it.mul;
@@ -496,6 +509,12 @@ __device__ __forceinline__ void bwd_item(const float* __restrict__ x, const floa
         float* o = dx + (size_t)node * d_in + it.x_off + u * D1;
 #pragma unroll
         for (int m1 = 0; m1 < D1; ++m1) o[m1] = gx[m1];
+        if (dx_t) {  // second copy, channel-contiguous: in1 block as [2l1+1][n_nodes][mul]
+            float* ot = dx_t + (size_t)it.x_off * n_nodes + (size_t)node * it.mul + u;
+            const size_t plane = (size_t)n_nodes * it.mul;
+#pragma unroll
+            for (int m1 = 0; m1 < D1; ++m1) ot[m1 * plane] = gx[m1];
+        }
     }
 }
 
@@ -508,7 +527,7 @@ __global__ __launch_bounds__(256) void tfc_conv_bwd_kernel(
     const int* __restrict__ eid, const int* __restrict__ nbr, const PathDev* __restrict__ paths,
     const BwdItem* __restrict__ items, const int* __restrict__ grp_paths, int n_items, long n_tasks,
     int d_in, int d_out, int w_numel, int msz, int py, float scale, float* __restrict__ dx,
-    float* __restrict__ dw, float* __restrict__ dyp, int n_nodes, int group) {
+    float* __restrict__ dw, float* __restrict__ dyp, int n_nodes, int group, float* __restrict__ dx_t) {
     const unsigned vb = tfc_xcd_remap(blockIdx.x, gridDim.x);
     const int wave = tfc_uniform((int)(threadIdx.x >> 6));
     const int lane = threadIdx.x & 63;
@@ -525,22 +544,22 @@ __global__ __launch_bounds__(256) void tfc_conv_bwd_kernel(
         case 0:
             if constexpr (0 <= LM)
                 bwd_item<0, NEED_DY, LM>(x, w, gout, M, cgd, eid, nbr, paths, grp_paths, it, beg, end, node, lane,
-                                 d_in, d_out, w_numel, msz, py, scale, dx, dw, dyp);
+                                 d_in, d_out, w_numel, msz, py, scale, dx, dw, dyp, dx_t, n_nodes);
             break;
         case 1:
             if constexpr (1 <= LM)
                 bwd_item<1, NEED_DY, LM>(x, w, gout, M, cgd, eid, nbr, paths, grp_paths, it, beg, end, node, lane,
-                                 d_in, d_out, w_numel, msz, py, scale, dx, dw, dyp);
+                                 d_in, d_out, w_numel, msz, py, scale, dx, dw, dyp, dx_t, n_nodes);
             break;
         case 2:
             if constexpr (2 <= LM)
                 bwd_item<2, NEED_DY, LM>(x, w, gout, M, cgd, eid, nbr, paths, grp_paths, it, beg, end, node, lane,
-                                 d_in, d_out, w_numel, msz, py, scale, dx, dw, dyp);
+                                 d_in, d_out, w_numel, msz, py, scale, dx, dw, dyp, dx_t, n_nodes);
             break;
         case 3:
             if constexpr (3 <= LM)
                 bwd_item<3, NEED_DY, LM>(x, w, gout, M, cgd, eid, nbr, paths, grp_paths, it, beg, end, node, lane,
-                                 d_in, d_out, w_numel, msz, py, scale, dx, dw, dyp);
+                                 d_in, d_out, w_numel, msz, py, scale, dx, dw, dyp, dx_t, n_nodes);
             break;
         default: break;
     }
@@ -773,7 +792,40 @@ extern "C" int tfc_conv_plan_create(const tfc_path* paths, int32_t n_paths, int3
 extern "C" int tfc_conv_plan_destroy(tfc_conv_plan* plan) {
     if (!plan) return TFC_OK;
     if (plan->blob) (void)hipFree(plan->blob);
+    if (plan->tout) (void)hipFree(plan->tout);
     delete plan;
+    return TFC_OK;
+}
+
+extern "C" int tfc_conv_plan_set_out_blocks(tfc_conv_plan* pl, const tfc_ir_block* blocks, int32_t n_blocks) {
+    TFC_REQUIRE(pl && blocks && n_blocks > 0, TFC_EINVAL, "tfc_conv_plan_set_out_blocks: null argument");
+    std::vector<PathDev> pd(pl->n_paths);
+    TFC_HIP(hipMemcpy(pd.data(), pl->paths, sizeof(PathDev) * pd.size(), hipMemcpyDeviceToHost));
+    std::vector<int> t(3 * (size_t)pl->n_paths);
+    for (int i = 0; i < pl->n_paths; ++i) {
+        const PathDev& p = pd[i];
+        const int d3 = 2 * p.l3 + 1;
+        int found = -1;
+        for (int b = 0; b < n_blocks; ++b) {
+            const tfc_ir_block& k = blocks[b];
+            TFC_REQUIRE(k.off >= 0 && k.mul > 0 && k.dim > 0 && (long)k.off + (long)k.mul * k.dim <= pl->d_out, TFC_EINVAL,
+                        "tfc_conv_plan_set_out_blocks: block %d outside the output row", b);
+            if (p.out_off >= k.off && p.out_off + p.mul * d3 <= k.off + k.mul * k.dim) found = b;
+        }
+        TFC_REQUIRE(found >= 0, TFC_EINVAL, "tfc_conv_plan_set_out_blocks: the output of path %d lies in no block", i);
+        const tfc_ir_block& k = blocks[found];
+        TFC_REQUIRE(k.dim == d3 && (p.out_off - k.off) % d3 == 0, TFC_EINVAL,
+                    "tfc_conv_plan_set_out_blocks: path %d (l3=%d) does not fit block %d (dim %d)", i, p.l3, found, k.dim);
+        t[3 * i] = k.off;
+        t[3 * i + 1] = k.mul;
+        t[3 * i + 2] = (p.out_off - k.off) / d3;
+    }
+    int dev = 0;
+    TFC_HIP(hipGetDevice(&dev));
+    TFC_REQUIRE(dev == pl->device, TFC_EINVAL, "tfc_conv_plan_set_out_blocks: plan lives on device %d, current is %d",
+                pl->device, dev);
+    if (!pl->tout) TFC_HIP(hipMalloc(&pl->tout, sizeof(int) * t.size()));
+    TFC_HIP(hipMemcpy(pl->tout, t.data(), sizeof(int) * t.size(), hipMemcpyHostToDevice));
     return TFC_OK;
 }
 
@@ -840,9 +892,16 @@ static int conv_group(int which, long n_nodes, int n_items = 1, int d_out = 1) {
 
 extern "C" int tfc_conv_fwd_m(const tfc_conv_plan* pl, const float* x, const float* M, const float* w,
                               const int32_t* row_ptr, const int32_t* eid, const int32_t* nbr, int64_t n_nodes,
-                              int64_t n_edges, float scale, float* out, tfc_stream_t stream_) {
+                              int64_t n_edges, float scale, float* out, tfc_stream_t stream) {
+    return tfc_conv_fwd_m_t(pl, x, M, w, row_ptr, eid, nbr, n_nodes, n_edges, scale, out, nullptr, stream);
+}
+
+extern "C" int tfc_conv_fwd_m_t(const tfc_conv_plan* pl, const float* x, const float* M, const float* w,
+                                const int32_t* row_ptr, const int32_t* eid, const int32_t* nbr, int64_t n_nodes,
+                                int64_t n_edges, float scale, float* out, float* out_t, tfc_stream_t stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     TFC_REQUIRE(pl, TFC_EINVAL, "tfc_conv_fwd: null plan");
+    TFC_REQUIRE(!out_t || pl->tout, TFC_EINVAL, "tfc_conv_fwd: out_t needs tfc_conv_plan_set_out_blocks first");
     TFC_REQUIRE(n_nodes >= 0 && n_edges >= 0, TFC_EINVAL, "tfc_conv_fwd: negative size");
     TFC_REQUIRE(n_nodes < (1LL << 31) && n_edges < (1LL << 31), TFC_EUNSUPPORTED,
                 "tfc_conv_fwd: more than 2^31 nodes or edges");
@@ -856,7 +915,7 @@ extern "C" int tfc_conv_fwd_m(const tfc_conv_plan* pl, const float* x, const flo
         TfcProfScope prof("tfc_conv_fwd_kernel", stream);
         tfc_conv_fwd_kernel<<<(unsigned)n_blocks, 256, 0, stream>>>(
             x, w, M, row_ptr, eid, nbr, pl->paths, pl->fwd_items, pl->n_fwd_items, n_tasks, pl->d_in, pl->d_out,
-            pl->w_numel, pl->msz, scale, out, (int)n_nodes, conv_group(0, n_nodes));
+            pl->w_numel, pl->msz, scale, out, (int)n_nodes, conv_group(0, n_nodes), pl->tout, out_t);
     }
     TFC_LAUNCH_CHECK("tfc_conv_fwd_kernel");
     return TFC_OK;
@@ -909,7 +968,15 @@ extern "C" int64_t tfc_conv_dy_floats(const tfc_conv_plan* plan, int64_t n_edges
 extern "C" int tfc_conv_bwd_m(const tfc_conv_plan* pl, const float* x, const float* M, const float* w,
                               const float* gout, const int32_t* row_ptr, const int32_t* eid, const int32_t* nbr,
                               int64_t n_nodes, int64_t n_edges, float scale, float* dx, float* dw, float* dy,
-                              float* dyp, tfc_stream_t stream_) {
+                              float* dyp, tfc_stream_t stream) {
+    return tfc_conv_bwd_m_t(pl, x, M, w, gout, row_ptr, eid, nbr, n_nodes, n_edges, scale, dx, nullptr, dw, dy, dyp,
+                            stream);
+}
+
+extern "C" int tfc_conv_bwd_m_t(const tfc_conv_plan* pl, const float* x, const float* M, const float* w,
+                                const float* gout, const int32_t* row_ptr, const int32_t* eid, const int32_t* nbr,
+                                int64_t n_nodes, int64_t n_edges, float scale, float* dx, float* dx_t, float* dw,
+                                float* dy, float* dyp, tfc_stream_t stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     TFC_REQUIRE(pl, TFC_EINVAL, "tfc_conv_bwd: null plan");
     TFC_REQUIRE(n_nodes >= 0 && n_edges >= 0, TFC_EINVAL, "tfc_conv_bwd: negative size");
@@ -933,7 +1000,7 @@ extern "C" int tfc_conv_bwd_m(const tfc_conv_plan* pl, const float* x, const flo
     tfc_conv_bwd_kernel<DY, LM><<<(unsigned)n_blocks, 256, 0, stream>>>(                                \
         x, w, gout, M, pl->cgd, row_ptr, eid, nbr, pl->paths, pl->bwd_items, pl->grp_paths, pl->n_bwd_items, \
         n_tasks, pl->d_in, pl->d_out, pl->w_numel, pl->msz, pl->py, scale, dx, dw, dy ? dyp : nullptr,  \
-        (int)n_nodes, conv_group(1, n_nodes, pl->n_bwd_items, pl->d_out))
+        (int)n_nodes, conv_group(1, n_nodes, pl->n_bwd_items, pl->d_out), dx_t)
     {
         TfcProfScope prof("tfc_conv_bwd_kernel", stream);
         if (dy) {

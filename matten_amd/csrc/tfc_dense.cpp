@@ -98,18 +98,26 @@ extern "C" int64_t tfc_linear_workspace_floats(const tfc_linear_ins* ins, int32_
 
 extern "C" int tfc_linear_fwd(const tfc_linear_ins* ins, int32_t n_ins, const float* x, const float* weight,
                               int64_t n_rows, int32_t d_in, int32_t d_out, int64_t weight_numel, float* xt,
-                              float* out, tfc_stream_t stream_) {
+                              float* out, tfc_stream_t stream) {
+    return tfc_linear_fwd_t(ins, n_ins, x, weight, n_rows, d_in, d_out, weight_numel, xt, 0, out, stream);
+}
+
+extern "C" int tfc_linear_fwd_t(const tfc_linear_ins* ins, int32_t n_ins, const float* x, const float* weight,
+                                int64_t n_rows, int32_t d_in, int32_t d_out, int64_t weight_numel, float* xt,
+                                int32_t xt_ready, float* out, tfc_stream_t stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     TFC_REQUIRE(n_rows >= 0 && d_in > 0 && d_out > 0, TFC_EINVAL, "tfc_linear_fwd: bad size");
     int rc = check_ins(ins, n_ins, d_in, d_out, weight_numel, "tfc_linear_fwd");
     if (rc != TFC_OK) return rc;
     if (n_rows == 0) return TFC_OK;
-    TFC_REQUIRE(x && weight && xt && out, TFC_EINVAL, "tfc_linear_fwd: null tensor");
+    TFC_REQUIRE((x || xt_ready) && weight && xt && out, TFC_EINVAL, "tfc_linear_fwd: null tensor");
     const long n = n_rows;
-    std::vector<tfc_ir_block> blocks;
-    for (int i = 0; i < n_ins; ++i) blocks.push_back(tfc_ir_block{ins[i].in_off, ins[i].mul_in, ins[i].dim});
-    rc = transpose_blocks(x, n, d_in, blocks, xt, stream);
-    if (rc != TFC_OK) return rc;
+    if (!xt_ready) {
+        std::vector<tfc_ir_block> blocks;
+        for (int i = 0; i < n_ins; ++i) blocks.push_back(tfc_ir_block{ins[i].in_off, ins[i].mul_in, ins[i].dim});
+        rc = transpose_blocks(x, n, d_in, blocks, xt, stream);
+        if (rc != TFC_OK) return rc;
+    }
     // out[(k, n), w] = pw * sum_u xt[k][n][u] W[u][w]     rows r = n * dim + k
     return run_waves(
         ins, n_ins, [](const tfc_linear_ins& q) { return q.out_off; },

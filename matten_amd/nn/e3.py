@@ -291,7 +291,8 @@ class UVUTensorProductCore(torch.nn.Module):
             w_off += m1.mul * m2.mul
         self.weight_numel = w_off
         self.plan = (
-            ops.ConvPlan([p for p in paths if p["mul"] > 0], self.irreps_in1.dim, self.irreps_in2.dim, self.irreps_out.dim, w_off)
+            ops.ConvPlan([p for p in paths if p["mul"] > 0], self.irreps_in1.dim, self.irreps_in2.dim, self.irreps_out.dim, w_off,
+                         out_blocks=_row_blocks(self.irreps_out.simplify()))  # the blocks of the o3.Linear that follows
             if self._unsupported is None
             else None
         )

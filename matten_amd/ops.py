@@ -248,10 +248,14 @@ class ConvPlan:
     """Host handle of a tfc_conv_plan (device tables live on the device that was current
     when the plan was first used)."""
 
-    def __init__(self, paths: Sequence[dict], d_in: int, d_sh: int, d_out: int, w_numel: int):
+    def __init__(self, paths: Sequence[dict], d_in: int, d_sh: int, d_out: int, w_numel: int, out_blocks=None):
         self.paths = [dict(p) for p in paths]
         self.d_in, self.d_sh, self.d_out, self.w_numel = int(d_in), int(d_sh), int(d_out), int(w_numel)
         self._handles = {}
+        # (off, mul, dim) blocks of the output row: with them the kernels also write the channel-contiguous
+        # copies the neighbouring o3.Linear layers read (tfc_conv_fwd_m_t / tfc_conv_bwd_m_t)
+        self.out_blocks = tuple(sorted(set(out_blocks))) if out_blocks and CONV_TRANSPOSED else None
+        self.in_blocks = tuple(sorted({(p["x_off"], p["mul"], 2 * p["l1"] + 1) for p in self.paths}))
 
     def handle(self, device: torch.device):
         idx = device.index if device.index is not None else torch.cuda.current_device()
@@ -267,6 +271,11 @@ class ConvPlan:
                 _lib.check(
                     _lib.lib().tfc_conv_plan_create(arr, len(self.paths), self.d_in, self.d_sh, self.d_out, self.w_numel, C.byref(out))
                 )
+                if self.out_blocks:
+                    barr = (IrBlock * len(self.out_blocks))()
+                    for b, (off, mul, dim) in zip(barr, self.out_blocks):
+                        b.off, b.mul, b.dim = off, mul, dim
+                    _lib.check(_lib.lib().tfc_conv_plan_set_out_blocks(out, barr, len(barr)))
             h = out
             self._handles[idx] = h
         return h
@@ -295,13 +304,16 @@ def _conv_fwd_raw(x, y, w, plan: ConvPlan, ordering, fwd_rows, n_out: int, scale
     if rp.numel() != n_out + 1:
         raise ValueError("conv: ordering does not match the number of output rows")
     out = torch.empty(n_out, plan.d_out, dtype=torch.float32, device=x.device)
+    out_t = torch.empty(n_out * plan.d_out, dtype=torch.float32, device=x.device) if plan.out_blocks and n_out else None
     M = ordering.m_matrices(plan, y, fwd_rows)
     _lib.check(
-        _lib.lib().tfc_conv_fwd_m(
+        _lib.lib().tfc_conv_fwd_m_t(
             plan.handle(x.device), _ptr(x), _ptr(M), _ptr(w), _ptr(rp), _ptr(eid), _ptr(nbr), n_out, E,
-            float(scale), _ptr(out), _stream(),
+            float(scale), _ptr(out), _ptr(out_t), _stream(),
         )
     )
+    if out_t is not None:
+        _transposed_put(out, plan.out_blocks, out_t)
     return out, x, y, w
 
 
@@ -316,12 +328,15 @@ def _conv_bwd_raw(gout, x, y, w, plan: ConvPlan, ordering, bwd_rows, scale: floa
     h = plan.handle(x.device)
     M = ordering.m_matrices(plan, y, bwd_rows)
     dyp = torch.empty(int(L.tfc_conv_dy_floats(h, E)), dtype=torch.float32, device=x.device) if need_dy else None
+    dx_t = torch.empty(x.numel(), dtype=torch.float32, device=x.device) if plan.out_blocks and x.numel() else None
     _lib.check(
-        L.tfc_conv_bwd_m(
+        L.tfc_conv_bwd_m_t(
             h, _ptr(x), _ptr(M), _ptr(w), _ptr(gout), _ptr(rp), _ptr(eid), _ptr(nbr),
-            x.shape[0], E, scale, _ptr(dx), _ptr(dw), _ptr(dy), _ptr(dyp), _stream(),
+            x.shape[0], E, scale, _ptr(dx), _ptr(dx_t), _ptr(dw), _ptr(dy), _ptr(dyp), _stream(),
         )
     )
+    if dx_t is not None:  # holds the in1 blocks only: serves a consumer that asks for (a subset of) those
+        _transposed_put(dx, plan.in_blocks, dx_t)
     return dx, dy, dw
 
 
@@ -786,6 +801,8 @@ def _gemm_workspace(n_floats: int) -> torch.Tensor:
 # which slows down by more than is gained - config 3: 3.71 -> 3.85 ms.)  TFC_MLP_SIDE_STREAM=0 keeps
 # everything on one stream.
 MLP_SIDE_STREAM = _os_environ.get("TFC_MLP_SIDE_STREAM", "1") != "0"
+# the convolution kernels also write the channel-contiguous copy of their result that the next o3.Linear reads
+CONV_TRANSPOSED = _os_environ.get("TFC_CONV_TRANSPOSED", "1") != "0"
 # the next layer's radial network right behind the current one's (TFC_MLP_PREFETCH=0: each layer its own)
 MLP_PREFETCH = _os_environ.get("TFC_MLP_PREFETCH", "1") != "0"
 # layers computed ahead.  1: more would not shorten the step (config 3: 3.44 ms either way) and moves the
@@ -869,33 +886,53 @@ def _gemm_waves(items):
 _TRANSPOSED: "dict[tuple, tuple]" = {}
 
 
+def _transposed_key(t: torch.Tensor):
+    return (t.data_ptr(), t._version, t.shape[0], t.shape[1])
+
+
+def _transposed_put(t: torch.Tensor, blocks, out: torch.Tensor):
+    """Remember `out` as the channel-contiguous copy of the `blocks` of the rows of `t` (made by _ir_transpose or
+    written by the kernel that produced `t`).  The last three are kept, each with its source, so that the
+    source's address cannot be reused while the entry lives."""
+    key = _transposed_key(t)
+    _TRANSPOSED.pop(key, None)
+    while len(_TRANSPOSED) >= 3:
+        _TRANSPOSED.pop(next(iter(_TRANSPOSED)))
+    cur = torch.cuda.current_stream(t.device)
+    ev = None
+    if MLP_SIDE_STREAM:  # the consumers of a tensor may run on different streams
+        ev = torch.cuda.Event()
+        ev.record(cur)
+    _TRANSPOSED[key] = (t.detach(), out, ev, cur, frozenset(blocks))
+
+
+def _transposed_get(t: torch.Tensor, blocks):
+    hit = _TRANSPOSED.get(_transposed_key(t))
+    if hit is None or not frozenset(blocks) <= hit[4]:
+        return None
+    cur = torch.cuda.current_stream(t.device)
+    if hit[2] is not None and hit[3] != cur:  # made on another stream: order this one after it
+        cur.wait_event(hit[2])
+        hit[1].record_stream(cur)
+    return hit[1]
+
+
 def _ir_transpose(t: torch.Tensor, blocks) -> torch.Tensor:
     """Channel-contiguous copy of the (off, mul, dim) blocks of the rows of `t` (tfc_ir_transpose):
-    block b of the flat result starts at off_b * N and is laid out [dim_b][N][mul_b].  The last two
-    results are kept (with their source, so its address cannot be reused): the gradient that reaches
-    the self connection and linear_2 of a layer is one tensor, transposed once."""
+    block b of the flat result starts at off_b * N and is laid out [dim_b][N][mul_b].  Results are kept for a
+    while (_transposed_put): the gradient that reaches the self connection and linear_2 of a layer is one
+    tensor, transposed once, and the convolution kernels hand the copies of their own results over this way."""
     n, d_row = t.shape
     blocks = tuple(sorted(set(blocks)))
-    key = (t.data_ptr(), t._version, n, d_row, blocks)
-    hit = _TRANSPOSED.get(key)
-    cur = torch.cuda.current_stream(t.device)
+    hit = _transposed_get(t, blocks)
     if hit is not None:
-        if hit[2] is not None and hit[3] != cur:  # made on another stream: order this one after it
-            cur.wait_event(hit[2])
-            hit[1].record_stream(cur)
-        return hit[1]
+        return hit
     arr = (IrBlock * len(blocks))()
     for a, (off, mul, dim) in zip(arr, blocks):
         a.off, a.mul, a.dim = off, mul, dim
     out = torch.empty(max(n * d_row, 1), dtype=torch.float32, device=t.device)
     _lib.check(_lib.lib().tfc_ir_transpose(_ptr(t), n, d_row, arr, len(blocks), _ptr(out), _stream()))
-    while len(_TRANSPOSED) >= 2:
-        _TRANSPOSED.pop(next(iter(_TRANSPOSED)))
-    ev = None
-    if MLP_SIDE_STREAM:  # the two consumers of a tensor may run on different streams
-        ev = torch.cuda.Event()
-        ev.record(cur)
-    _TRANSPOSED[key] = (t.detach(), out, ev, cur)
+    _transposed_put(t, blocks, out)
     return out
 
 
@@ -966,11 +1003,14 @@ class _LinearFn(torch.autograd.Function):
             raise ValueError(f"linear: x{tuple(x.shape)} / weight[{weight.numel()}] do not match the irreps ({spec.d_in}, {spec.weight_numel})")
         alloc = torch.empty if spec.out_covered else torch.zeros
         out = alloc(n, spec.d_out, dtype=torch.float32, device=x.device)
-        xt = torch.empty(max(n * spec.d_in, 1), dtype=torch.float32, device=x.device)
+        xt = _transposed_get(x, _linear_in_blocks(spec)) if spec.instructions and n else None
+        ready = xt is not None  # the kernel that produced x wrote the copy as well
+        if xt is None:
+            xt = torch.empty(max(n * spec.d_in, 1), dtype=torch.float32, device=x.device)
         if spec.instructions:
             ins = _linear_ins(spec)
-            _lib.check(_lib.lib().tfc_linear_fwd(ins, len(ins), _ptr(x), _ptr(weight), n, spec.d_in, spec.d_out, spec.weight_numel,
-                                                 _ptr(xt), _ptr(out), _stream()))
+            _lib.check(_lib.lib().tfc_linear_fwd_t(ins, len(ins), _ptr(x), _ptr(weight), n, spec.d_in, spec.d_out,
+                                                   spec.weight_numel, _ptr(xt), 1 if ready else 0, _ptr(out), _stream()))
         ctx.save_for_backward(xt, weight, x)
         ctx.spec, ctx.n = spec, n
         return out

@@ -945,3 +945,77 @@ def test_conv_fwd_with_last_mlp_layer_folded_in(device):
     assert rel(got, shipped) < TOL
     assert L.tfc_conv_fwd_fused_m(plan.handle(xg.device), P(xg), P(M), P(hg), P(wg), 32, 0.125, P(rows[0]), P(rows[1]), P(rows[2]), n_nodes,
                                   n_edges, 0.3, P(got), st) == -2
+
+
+@pytest.mark.parametrize("in1,mid", [("32x0e+16x1o+8x2e", "32x0o+32x0e+16x1o+16x1e+8x2o+8x2e"), ("100x0e+70x1o", "100x0e+70x1o+70x1e")])
+def test_conv_channel_contiguous_copies(device, in1, mid):
+    """tfc_conv_fwd_m_t / tfc_conv_bwd_m_t: the second, channel-contiguous copy of out / dx is bit-identical to
+    tfc_ir_transpose of the first one, block by block, and the o3.Linear that follows picks it up
+    (tfc_linear_fwd_t with xt_ready) with a bit-identical result."""
+    from matten_amd import _lib, ops
+    from matten_amd.nn.e3 import Linear
+    from matten_amd.nn.utils import UVUTensorProduct
+
+    torch.manual_seed(50)
+    h = UVUTensorProduct(in1, "0e+1o+2e", mid, mlp_input_size=4)
+    plan = h.tp.plan
+    assert plan.out_blocks
+    n, e = 41, 1100
+    ei = random_graph(n, e, 51, device)
+    o = ops.EdgeOrdering(ei, n)
+    x = torch.randn(n, plan.d_in, device=device)
+    y = torch.randn(e, plan.d_sh, device=device)
+    w = torch.randn(e, plan.w_numel, device=device)
+    L, P, st = _lib.lib(), ops._ptr, ops._stream()
+    hd = plan.handle(x.device)
+    M = o.m_matrices(plan, y, o.by_dst)
+    out = torch.empty(n, plan.d_out, device=device)
+    out_t = torch.full((n * plan.d_out,), float("nan"), device=device)
+    rp, eid, nbr = o.by_dst
+    _lib.check(L.tfc_conv_fwd_m_t(hd, P(x), P(M), P(w), P(rp), P(eid), P(nbr), n, e, 0.7, P(out), P(out_t), st))
+    out_plain = torch.empty_like(out)
+    _lib.check(L.tfc_conv_fwd_m(hd, P(x), P(M), P(w), P(rp), P(eid), P(nbr), n, e, 0.7, P(out_plain), st))
+    assert torch.equal(out, out_plain)
+    ops.clear_caches()
+    assert torch.equal(out_t, ops._ir_transpose(out, plan.out_blocks))  # the blocks tile the row: every element is set
+
+    go = torch.randn(n, plan.d_out, device=device)
+    rp, eid, nbr = o.by_src
+    dx, dw, dy = torch.empty_like(x), torch.empty_like(w), torch.empty_like(y)
+    dyp = torch.empty(int(L.tfc_conv_dy_floats(hd, e)), device=device)
+    dx_t = torch.full((x.numel(),), float("nan"), device=device)
+    _lib.check(L.tfc_conv_bwd_m_t(hd, P(x), P(M), P(w), P(go), P(rp), P(eid), P(nbr), n, e, 0.7, P(dx), P(dx_t), P(dw), P(dy), P(dyp), st))
+    dx2, dw2, dy2 = torch.empty_like(x), torch.empty_like(w), torch.empty_like(y)
+    _lib.check(L.tfc_conv_bwd_m(hd, P(x), P(M), P(w), P(go), P(rp), P(eid), P(nbr), n, e, 0.7, P(dx2), P(dw2), P(dy2), P(dyp), st))
+    assert torch.equal(dx, dx2) and torch.equal(dw, dw2) and torch.equal(dy, dy2)
+    ops.clear_caches()
+    assert torch.equal(dx_t, ops._ir_transpose(dx, plan.in_blocks))
+
+    # a null second copy without blocks is fine; a non-null one before tfc_conv_plan_set_out_blocks is refused
+    bare = ops.ConvPlan(plan.paths, plan.d_in, plan.d_sh, plan.d_out, plan.w_numel)
+    rp, eid, nbr = o.by_dst
+    assert L.tfc_conv_fwd_m_t(bare.handle(x.device), P(x), P(M), P(w), P(rp), P(eid), P(nbr), n, e, 0.7, P(out), P(out_t), st) < 0
+    bad = (_lib.IrBlock * 1)()
+    bad[0].off, bad[0].mul, bad[0].dim = 0, plan.d_out // 5, 5  # paths with l3 = 0 do not fit a 5-wide block
+    assert L.tfc_conv_plan_set_out_blocks(bare.handle(x.device), bad, 1) < 0
+
+    # end to end: conv -> o3.Linear with and without the hand-over, forward and backward
+    lin = Linear(h.irreps_out, "24x0e+12x1o+6x2e").to(device)
+    res = {}
+    for on in (True, False):
+        ops.clear_caches()
+        p2 = ops.ConvPlan(plan.paths, plan.d_in, plan.d_sh, plan.d_out, plan.w_numel, out_blocks=plan.out_blocks if on else None)
+        xr = x.clone().requires_grad_(True)
+        pre = Linear(in1, in1).to(device)
+        torch.manual_seed(52)
+        with torch.no_grad():
+            pre.weight.copy_(torch.randn_like(pre.weight))
+        msg = ops.conv(pre(xr), y, w, p2, o, 0.7)
+        hit = ops._transposed_get(msg, ops._linear_in_blocks(lin.spec))
+        assert (hit is not None) == on
+        z = lin(msg)
+        gz = torch.Generator().manual_seed(53)
+        gx, gw1, gw2 = torch.autograd.grad(z, [xr, pre.weight, lin.weight], torch.randn(z.shape, generator=gz).to(device))
+        res[on] = (z.detach(), gx, gw1, gw2)
+    for a, b in zip(res[True], res[False]):
+        assert torch.equal(a, b)
