@@ -485,6 +485,16 @@ int tfc_gate_fwd(const tfc_gate_seg* segs, int32_t n_segs, const float* x, int64
                  int32_t d_in, int32_t d_out, float* out, tfc_stream_t stream);
 int tfc_gate_bwd(const tfc_gate_seg* segs, int32_t n_segs, const float* x, const float* gout,
                  int64_t n_rows, int32_t d_in, int32_t d_out, float* dx, tfc_stream_t stream);
+/* The same two calls writing a second, channel-contiguous copy of their result (see tfc_conv_fwd_m_t): the
+ * (off, mul, dim) `blocks` of the out / dx row go to out_t / dx_t in the layout of tfc_ir_transpose, for the
+ * o3.Linear / self connection of the next layer (forward) or of this layer's update (backward).  A null
+ * out_t / dx_t makes them the plain calls. */
+int tfc_gate_fwd_t(const tfc_gate_seg* segs, int32_t n_segs, const float* x, int64_t n_rows, int32_t d_in,
+                   int32_t d_out, float* out, const struct tfc_ir_block* blocks, int32_t n_blocks, float* out_t,
+                   tfc_stream_t stream);
+int tfc_gate_bwd_t(const tfc_gate_seg* segs, int32_t n_segs, const float* x, const float* gout, int64_t n_rows,
+                   int32_t d_in, int32_t d_out, float* dx, const struct tfc_ir_block* blocks, int32_t n_blocks,
+                   float* dx_t, tfc_stream_t stream);
 
 /* Second order of the gate (double backward, see tfc_edge_encode_bwd2): tfc_gate_bwd returns dx = J(x)^T gout;
  * for a cotangent v [n_rows, d_in] of dx this returns ggout = J(x) v [n_rows, d_out] and

@@ -70,9 +70,30 @@ __device__ __forceinline__ float act_grad2(int act, float x) {  // second deriva
     }
 }
 
+// Second, channel-contiguous copy of a result row (the layout of tfc_ir_transpose): element c of row r, inside
+// block (off, mul, dim), goes to t[off * n_rows + (m * n_rows + r) * mul + u], c = off + u * dim + m.
+struct GateBlocks {
+    tfc_ir_block b[MAX_SEGS];
+    int n;
+};
+
+__device__ __forceinline__ void store_transposed(const GateBlocks& bl, long r, int c, long n_rows, float v,
+                                                 float* __restrict__ t) {
+    for (int k = 0; k < bl.n; ++k) {
+        const tfc_ir_block b = bl.b[k];
+        const int idx = c - b.off;
+        if (idx < 0 || idx >= b.mul * b.dim) continue;
+        const int u = idx / b.dim, m = idx - u * b.dim;
+        t[(long)b.off * n_rows + ((long)m * n_rows + r) * b.mul + u] = v;
+        return;
+    }
+}
+
+template <bool T>
 __global__ __launch_bounds__(256) void tfc_gate_fwd_kernel(const GateSegs g, const float* __restrict__ x,
                                                            long n_rows, int d_in, int d_out,
-                                                           float* __restrict__ out) {
+                                                           float* __restrict__ out, const GateBlocks bl,
+                                                           float* __restrict__ out_t) {
     const long total = n_rows * (long)d_out;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
          i += (long)gridDim.x * blockDim.x) {
@@ -93,12 +114,15 @@ __global__ __launch_bounds__(256) void tfc_gate_fwd_kernel(const GateSegs g, con
             break;
         }
         out[i] = v;
+        if (T) store_transposed(bl, r, c, n_rows, v, out_t);
     }
 }
 
+template <bool T>
 __global__ __launch_bounds__(256) void tfc_gate_bwd_kernel(const GateSegs g, const float* __restrict__ x,
                                                            const float* __restrict__ gout, long n_rows, int d_in,
-                                                           int d_out, float* __restrict__ dx) {
+                                                           int d_out, float* __restrict__ dx, const GateBlocks bl,
+                                                           float* __restrict__ dx_t) {
     const long total = n_rows * (long)d_in;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
          i += (long)gridDim.x * blockDim.x) {
@@ -129,6 +153,117 @@ __global__ __launch_bounds__(256) void tfc_gate_bwd_kernel(const GateSegs g, con
             }
         }
         dx[i] = v;
+        if (T) store_transposed(bl, r, c, n_rows, v, dx_t);
+    }
+}
+
+// The same two passes walking the rows copy by copy (one thread per (row, u) of a block, like tfc_ir_transpose):
+// the 2l+1 values of a copy are read and written as one contiguous run, the gate's activation is evaluated once
+// per copy, and the channel-contiguous copy gets one coalesced store per plane.  Needs blocks that tile the row.
+__device__ __forceinline__ bool find_copy(const GateBlocks& bl, int j, tfc_ir_block& b, int& u) {
+    for (int k = 0; k < bl.n; ++k) {
+        if (j < bl.b[k].mul) {
+            b = bl.b[k];
+            u = j;
+            return true;
+        }
+        j -= bl.b[k].mul;
+    }
+    return false;
+}
+
+constexpr int GATE_MAXD = 2 * TFC_LMAX + 1;
+
+__global__ __launch_bounds__(256) void tfc_gate_fwd_copies_kernel(const GateSegs g, const float* __restrict__ x,
+                                                                  long n_rows, int d_in, int d_out, int copies,
+                                                                  float* __restrict__ out, const GateBlocks bl,
+                                                                  float* __restrict__ out_t) {
+    const long total = n_rows * (long)copies;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long r = i / copies;
+        tfc_ir_block b;
+        int u;
+        if (!find_copy(bl, (int)(i - r * copies), b, u)) continue;
+        const int c0 = b.off + u * b.dim;
+        const float* xr = x + r * (long)d_in;
+        float v[GATE_MAXD];
+#pragma unroll
+        for (int m = 0; m < GATE_MAXD; ++m) v[m] = 0.f;
+        for (int s = 0; s < g.n; ++s) {
+            const tfc_gate_seg sg = g.s[s];
+            const int idx = c0 - sg.out_off;
+            if (idx < 0 || idx >= sg.count * sg.dim) continue;
+            if (sg.gate_off < 0) {
+                v[0] = sg.cst * act_eval(sg.act, xr[sg.in_off + idx]);
+            } else {
+                const float a = sg.cst * act_eval(sg.act, xr[sg.gate_off + idx / sg.dim]);
+#pragma unroll
+                for (int m = 0; m < GATE_MAXD; ++m)
+                    if (m < b.dim) v[m] = a * xr[sg.in_off + idx + m];
+            }
+            break;
+        }
+        float* o = out + r * (long)d_out + c0;
+        float* t = out_t + (long)b.off * n_rows + r * b.mul + u;
+        const long plane = n_rows * (long)b.mul;
+#pragma unroll
+        for (int m = 0; m < GATE_MAXD; ++m)
+            if (m < b.dim) {
+                o[m] = v[m];
+                t[m * plane] = v[m];
+            }
+    }
+}
+
+__global__ __launch_bounds__(256) void tfc_gate_bwd_copies_kernel(const GateSegs g, const float* __restrict__ x,
+                                                                  const float* __restrict__ gout, long n_rows,
+                                                                  int d_in, int d_out, int copies,
+                                                                  float* __restrict__ dx, const GateBlocks bl,
+                                                                  float* __restrict__ dx_t) {
+    const long total = n_rows * (long)copies;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long r = i / copies;
+        tfc_ir_block b;
+        int u;
+        if (!find_copy(bl, (int)(i - r * copies), b, u)) continue;
+        const int c0 = b.off + u * b.dim;
+        const float* xr = x + r * (long)d_in;
+        const float* gr = gout + r * (long)d_out;
+        float v[GATE_MAXD];
+#pragma unroll
+        for (int m = 0; m < GATE_MAXD; ++m) v[m] = 0.f;
+        for (int s = 0; s < g.n; ++s) {
+            const tfc_gate_seg sg = g.s[s];
+            const int idx = c0 - sg.in_off;
+            if (idx >= 0 && idx < sg.count * sg.dim) {
+                if (sg.gate_off < 0) {
+                    v[0] = gr[sg.out_off + idx] * sg.cst * act_grad(sg.act, xr[c0]);
+                } else {
+                    const float a = act_eval(sg.act, xr[sg.gate_off + idx / sg.dim]);
+#pragma unroll
+                    for (int m = 0; m < GATE_MAXD; ++m)
+                        if (m < b.dim) v[m] = gr[sg.out_off + idx + m] * sg.cst * a;  // (same rounding as per column)
+                }
+                break;
+            }
+            const int gu = c0 - sg.gate_off;
+            if (sg.gate_off >= 0 && gu >= 0 && gu < sg.count) {  // a gate scalar (its block has dim 1)
+                float dot = 0.f;
+                for (int m = 0; m < sg.dim; ++m)
+                    dot = fmaf(gr[sg.out_off + gu * sg.dim + m], xr[sg.in_off + gu * sg.dim + m], dot);
+                v[0] = dot * sg.cst * act_grad(sg.act, xr[c0]);
+                break;
+            }
+        }
+        float* o = dx + r * (long)d_in + c0;
+        float* t = dx_t + (long)b.off * n_rows + r * b.mul + u;
+        const long plane = n_rows * (long)b.mul;
+#pragma unroll
+        for (int m = 0; m < GATE_MAXD; ++m)
+            if (m < b.dim) {
+                o[m] = v[m];
+                t[m * plane] = v[m];
+            }
     }
 }
 
@@ -277,10 +412,53 @@ int pack_segs(const tfc_gate_seg* segs, int32_t n_segs, int32_t d_in, int32_t d_
     return TFC_OK;
 }
 
+int pack_blocks(const tfc_ir_block* blocks, int32_t n_blocks, int32_t d_row, const float* t, GateBlocks* out) {
+    out->n = 0;
+    if (!t) return TFC_OK;
+    TFC_REQUIRE(blocks && n_blocks > 0 && n_blocks <= MAX_SEGS, TFC_EINVAL, "tfc_gate: n_blocks=%d outside 1..%d",
+                n_blocks, MAX_SEGS);
+    for (int i = 0; i < n_blocks; ++i) {
+        const tfc_ir_block& b = blocks[i];
+        TFC_REQUIRE(b.off >= 0 && b.mul > 0 && b.dim > 0 && (long)b.off + (long)b.mul * b.dim <= d_row, TFC_EINVAL,
+                    "tfc_gate: block %d outside the row", i);
+        out->b[i] = b;
+    }
+    out->n = n_blocks;
+    return TFC_OK;
+}
+
+// copies per row when the blocks, in the order given, tile [0, d_row) with copies of at most GATE_MAXD values and no
+// segment boundary falls inside a copy; 0 otherwise (the per-column kernels then do the job)
+int tiling_copies(const GateBlocks& bl, int d_row, const GateSegs& g, bool in_side) {
+    int at = 0, copies = 0;
+    for (int k = 0; k < bl.n; ++k) {
+        const tfc_ir_block& b = bl.b[k];
+        if (b.off != at || b.dim > GATE_MAXD) return 0;
+        at += b.mul * b.dim;
+        copies += b.mul;
+        for (int s = 0; s < g.n; ++s) {
+            const tfc_gate_seg& sg = g.s[s];
+            const int so = in_side ? sg.in_off : sg.out_off;
+            const bool overlap = so < b.off + b.mul * b.dim && so + sg.count * sg.dim > b.off;
+            if (overlap && sg.count > 0 && (sg.dim != b.dim || (so - b.off) % b.dim != 0)) return 0;
+            if (in_side && sg.gate_off >= 0 && sg.count > 0 && sg.gate_off < b.off + b.mul * b.dim &&
+                sg.gate_off + sg.count > b.off && b.dim != 1)
+                return 0;
+        }
+    }
+    return at == d_row ? copies : 0;
+}
+
 }  // namespace
 
 extern "C" int tfc_gate_fwd(const tfc_gate_seg* segs, int32_t n_segs, const float* x, int64_t n_rows, int32_t d_in,
-                            int32_t d_out, float* out, tfc_stream_t stream_) {
+                            int32_t d_out, float* out, tfc_stream_t stream) {
+    return tfc_gate_fwd_t(segs, n_segs, x, n_rows, d_in, d_out, out, nullptr, 0, nullptr, stream);
+}
+
+extern "C" int tfc_gate_fwd_t(const tfc_gate_seg* segs, int32_t n_segs, const float* x, int64_t n_rows, int32_t d_in,
+                              int32_t d_out, float* out, const tfc_ir_block* blocks, int32_t n_blocks, float* out_t,
+                              tfc_stream_t stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     TFC_REQUIRE(n_rows >= 0 && d_in > 0 && d_out > 0, TFC_EINVAL, "tfc_gate_fwd: bad size");
     GateSegs g;
@@ -289,14 +467,30 @@ extern "C" int tfc_gate_fwd(const tfc_gate_seg* segs, int32_t n_segs, const floa
     if (n_rows == 0) return TFC_OK;
     TFC_REQUIRE(x && out, TFC_EINVAL, "tfc_gate_fwd: null tensor");
     const int grid = (int)std::min<long>((n_rows * (long)d_out + 255) / 256, 8192);
+    GateBlocks bl;
+    rc = pack_blocks(blocks, n_blocks, d_out, out_t, &bl);
+    if (rc) return rc;
     TfcProfScope prof("tfc_gate_fwd_kernel", stream);
-    tfc_gate_fwd_kernel<<<grid, 256, 0, stream>>>(g, x, (long)n_rows, d_in, d_out, out);
+    const int copies = out_t ? tiling_copies(bl, d_out, g, false) : 0;
+    if (copies > 0) {
+        const int cgrid = (int)std::min<long>((n_rows * (long)copies + 255) / 256, 8192);
+        tfc_gate_fwd_copies_kernel<<<cgrid, 256, 0, stream>>>(g, x, (long)n_rows, d_in, d_out, copies, out, bl, out_t);
+    } else if (out_t)
+        tfc_gate_fwd_kernel<true><<<grid, 256, 0, stream>>>(g, x, (long)n_rows, d_in, d_out, out, bl, out_t);
+    else
+        tfc_gate_fwd_kernel<false><<<grid, 256, 0, stream>>>(g, x, (long)n_rows, d_in, d_out, out, bl, nullptr);
     TFC_LAUNCH_CHECK("tfc_gate_fwd_kernel");
     return TFC_OK;
 }
 
 extern "C" int tfc_gate_bwd(const tfc_gate_seg* segs, int32_t n_segs, const float* x, const float* gout,
-                            int64_t n_rows, int32_t d_in, int32_t d_out, float* dx, tfc_stream_t stream_) {
+                            int64_t n_rows, int32_t d_in, int32_t d_out, float* dx, tfc_stream_t stream) {
+    return tfc_gate_bwd_t(segs, n_segs, x, gout, n_rows, d_in, d_out, dx, nullptr, 0, nullptr, stream);
+}
+
+extern "C" int tfc_gate_bwd_t(const tfc_gate_seg* segs, int32_t n_segs, const float* x, const float* gout,
+                              int64_t n_rows, int32_t d_in, int32_t d_out, float* dx, const tfc_ir_block* blocks,
+                              int32_t n_blocks, float* dx_t, tfc_stream_t stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     TFC_REQUIRE(n_rows >= 0 && d_in > 0 && d_out > 0, TFC_EINVAL, "tfc_gate_bwd: bad size");
     GateSegs g;
@@ -305,8 +499,18 @@ extern "C" int tfc_gate_bwd(const tfc_gate_seg* segs, int32_t n_segs, const floa
     if (n_rows == 0) return TFC_OK;
     TFC_REQUIRE(x && gout && dx, TFC_EINVAL, "tfc_gate_bwd: null tensor");
     const int grid = (int)std::min<long>((n_rows * (long)d_in + 255) / 256, 8192);
+    GateBlocks bl;
+    rc = pack_blocks(blocks, n_blocks, d_in, dx_t, &bl);
+    if (rc) return rc;
     TfcProfScope prof("tfc_gate_bwd_kernel", stream);
-    tfc_gate_bwd_kernel<<<grid, 256, 0, stream>>>(g, x, gout, (long)n_rows, d_in, d_out, dx);
+    const int copies = dx_t ? tiling_copies(bl, d_in, g, true) : 0;
+    if (copies > 0) {
+        const int cgrid = (int)std::min<long>((n_rows * (long)copies + 255) / 256, 8192);
+        tfc_gate_bwd_copies_kernel<<<cgrid, 256, 0, stream>>>(g, x, gout, (long)n_rows, d_in, d_out, copies, dx, bl, dx_t);
+    } else if (dx_t)
+        tfc_gate_bwd_kernel<true><<<grid, 256, 0, stream>>>(g, x, gout, (long)n_rows, d_in, d_out, dx, bl, dx_t);
+    else
+        tfc_gate_bwd_kernel<false><<<grid, 256, 0, stream>>>(g, x, gout, (long)n_rows, d_in, d_out, dx, bl, nullptr);
     TFC_LAUNCH_CHECK("tfc_gate_bwd_kernel");
     return TFC_OK;
 }

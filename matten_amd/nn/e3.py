@@ -247,7 +247,8 @@ class Gate(torch.nn.Module):
             out_off += mul * ir.dim
             u += mul
         self.irreps_out = Irreps(out_irreps)
-        self.spec = ops.GateSpec(d_in=self.irreps_in.dim, d_out=self.irreps_out.dim, segs=tuple(segs))
+        self.spec = ops.GateSpec(d_in=self.irreps_in.dim, d_out=self.irreps_out.dim, segs=tuple(segs),
+                                 in_blocks=_row_blocks(self.irreps_in), out_blocks=_row_blocks(self.irreps_out))
 
     def forward(self, x):
         return ops.gate(x, self.spec)

@@ -886,6 +886,16 @@ def _gemm_waves(items):
 _TRANSPOSED: "dict[tuple, tuple]" = {}
 
 
+@functools.lru_cache(maxsize=256)
+def _ir_blocks(blocks):
+    if not blocks:
+        return None
+    arr = (IrBlock * len(blocks))()
+    for a, (off, mul, dim) in zip(arr, blocks):
+        a.off, a.mul, a.dim = off, mul, dim
+    return arr
+
+
 def _transposed_key(t: torch.Tensor):
     return (t.data_ptr(), t._version, t.shape[0], t.shape[1])
 
@@ -1555,6 +1565,10 @@ class GateSpec:
     d_in: int
     d_out: int
     segs: Tuple[Tuple[int, int, int, int, int, int, float], ...]  # in_off,out_off,count,dim,gate_off,act,cst
+    # (off, mul, dim) blocks of the input / output row: when given, the kernels also write the
+    # channel-contiguous copy of dx / out for the o3.Linear that reads it next (tfc_gate_*_t)
+    in_blocks: Tuple[Tuple[int, int, int], ...] = ()
+    out_blocks: Tuple[Tuple[int, int, int], ...] = ()
 
     def c_array(self):
         arr = (GateSeg * len(self.segs))()
@@ -1569,8 +1583,14 @@ class _GateFn(torch.autograd.Function):
         x = _f32(x, "x")
         if x.shape[1] != spec.d_in:
             raise ValueError(f"gate: expected {spec.d_in} columns, got {x.shape[1]}")
-        out = torch.empty(x.shape[0], spec.d_out, dtype=torch.float32, device=x.device)
-        _lib.check(_lib.lib().tfc_gate_fwd(spec.c_array(), len(spec.segs), _ptr(x), x.shape[0], spec.d_in, spec.d_out, _ptr(out), _stream()))
+        n = x.shape[0]
+        out = torch.empty(n, spec.d_out, dtype=torch.float32, device=x.device)
+        blocks = spec.out_blocks if CONV_TRANSPOSED and n and len(spec.out_blocks) <= 32 else ()
+        out_t = torch.empty(n * spec.d_out, dtype=torch.float32, device=x.device) if blocks else None
+        _lib.check(_lib.lib().tfc_gate_fwd_t(spec.c_array(), len(spec.segs), _ptr(x), n, spec.d_in, spec.d_out, _ptr(out),
+                                             _ir_blocks(blocks), len(blocks), _ptr(out_t), _stream()))
+        if out_t is not None:
+            _transposed_put(out, blocks, out_t)
         ctx.save_for_backward(x)
         ctx.spec = spec
         return out
@@ -1586,7 +1606,13 @@ class _GateFn(torch.autograd.Function):
 def _gate_bwd_raw(x, g, spec: GateSpec):
     g = _f32(g, "grad_output")
     dx = torch.empty_like(x)
-    _lib.check(_lib.lib().tfc_gate_bwd(spec.c_array(), len(spec.segs), _ptr(x), _ptr(g), x.shape[0], spec.d_in, spec.d_out, _ptr(dx), _stream()))
+    n = x.shape[0]
+    blocks = spec.in_blocks if CONV_TRANSPOSED and n and len(spec.in_blocks) <= 32 else ()
+    dx_t = torch.empty(x.numel(), dtype=torch.float32, device=x.device) if blocks else None
+    _lib.check(_lib.lib().tfc_gate_bwd_t(spec.c_array(), len(spec.segs), _ptr(x), _ptr(g), n, spec.d_in, spec.d_out, _ptr(dx),
+                                         _ir_blocks(blocks), len(blocks), _ptr(dx_t), _stream()))
+    if dx_t is not None:
+        _transposed_put(dx, blocks, dx_t)
     return dx
 
 

@@ -1019,3 +1019,56 @@ def test_conv_channel_contiguous_copies(device, in1, mid):
         res[on] = (z.detach(), gx, gw1, gw2)
     for a, b in zip(res[True], res[False]):
         assert torch.equal(a, b)
+
+
+def test_gate_channel_contiguous_copies(device):
+    """tfc_gate_fwd_t / tfc_gate_bwd_t: the second copy equals tfc_ir_transpose of the first, which equals the
+    plain call's result."""
+    from matten_amd import _lib, ops
+    from matten_amd.nn.e3 import Gate
+
+    gate = Gate("20x0e+12x0o", ["ssp", "tanh"], "9x0e+7x0e", ["ssp", "silu"], "9x1o+7x2e")
+    spec = gate.spec
+    assert spec.in_blocks and spec.out_blocks
+    n = 77
+    g = torch.Generator().manual_seed(60)
+    x = torch.randn(n, spec.d_in, generator=g).to(device)
+    go = torch.randn(n, spec.d_out, generator=g).to(device)
+    L, P, st = _lib.lib(), ops._ptr, ops._stream()
+    out, out2 = torch.empty(n, spec.d_out, device=device), torch.empty(n, spec.d_out, device=device)
+    out_t = torch.full((n * spec.d_out,), float("nan"), device=device)
+    _lib.check(L.tfc_gate_fwd_t(spec.c_array(), len(spec.segs), P(x), n, spec.d_in, spec.d_out, P(out), ops._ir_blocks(spec.out_blocks), len(spec.out_blocks), P(out_t), st))
+    _lib.check(L.tfc_gate_fwd(spec.c_array(), len(spec.segs), P(x), n, spec.d_in, spec.d_out, P(out2), st))
+    assert torch.equal(out, out2)
+    ops.clear_caches()
+    assert torch.equal(out_t, ops._ir_transpose(out, spec.out_blocks))
+    dx, dx2 = torch.empty_like(x), torch.empty_like(x)
+    dx_t = torch.full((x.numel(),), float("nan"), device=device)
+    _lib.check(L.tfc_gate_bwd_t(spec.c_array(), len(spec.segs), P(x), P(go), n, spec.d_in, spec.d_out, P(dx), ops._ir_blocks(spec.in_blocks), len(spec.in_blocks), P(dx_t), st))
+    _lib.check(L.tfc_gate_bwd(spec.c_array(), len(spec.segs), P(x), P(go), n, spec.d_in, spec.d_out, P(dx2), st))
+    assert torch.equal(dx, dx2)
+    ops.clear_caches()
+    assert torch.equal(dx_t, ops._ir_transpose(dx, spec.in_blocks))
+    # blocks that do not tile the row take the per-column kernels: the listed blocks are written, the rest left alone
+    part = spec.out_blocks[1:]
+    out_p = torch.full((n * spec.d_out,), 7.0, device=device)
+    _lib.check(L.tfc_gate_fwd_t(spec.c_array(), len(spec.segs), P(x), n, spec.d_in, spec.d_out, P(out2), ops._ir_blocks(part), len(part), P(out_p), st))
+    assert torch.equal(out, out2)
+    off0, mul0, dim0 = spec.out_blocks[0]
+    lo, hi = off0 * n, (off0 + mul0 * dim0) * n
+    assert torch.all(out_p[lo:hi] == 7.0) and torch.equal(out_p[hi:], out_t[hi:]) and torch.equal(out_p[:lo], out_t[:lo])
+    part = spec.in_blocks[:-1]
+    dx_p = torch.full((x.numel(),), 7.0, device=device)
+    _lib.check(L.tfc_gate_bwd_t(spec.c_array(), len(spec.segs), P(x), P(go), n, spec.d_in, spec.d_out, P(dx2), ops._ir_blocks(part), len(part), P(dx_p), st))
+    offl, mull, diml = spec.in_blocks[-1]
+    assert torch.equal(dx, dx2) and torch.equal(dx_p[: offl * n], dx_t[: offl * n]) and torch.all(dx_p[offl * n :] == 7.0)
+    # the module route hands the copies over
+    ops.clear_caches()
+    xr = x.clone().requires_grad_(True)
+    y = gate(xr)
+    assert ops._transposed_get(y, spec.out_blocks) is not None
+    (gx,) = torch.autograd.grad(y, xr, go)
+    assert torch.equal(gx, dx) and ops._transposed_get(gx, spec.in_blocks) is not None
+    bad = (_lib.IrBlock * 1)()
+    bad[0].off, bad[0].mul, bad[0].dim = spec.d_out - 2, 2, 3
+    assert L.tfc_gate_fwd_t(spec.c_array(), len(spec.segs), P(x), n, spec.d_in, spec.d_out, P(out), bad, 1, P(out_t), st) < 0
