@@ -445,6 +445,13 @@ int tfc_fctp_bwd(const tfc_fctp_ins* ins, int32_t n_ins, const float* x, const f
                  float* gt, int32_t gt_ready, float* dx, float* dw, float* da, float* xt, float* da_part,
                  float* workspace, int64_t workspace_floats, tfc_stream_t stream);
 
+/* Last step of the attribute gradient when the node attributes are rows of a per-class table (a = table[cls],
+ * eigenn/nn/embedding.py:59-75): every row receives the mean gradient of its class,
+ *     da[n, v] = inv_count[cls[n]] * sum_i part[i, cls[n], v]      (part [n_parts, r, d_a], i ascending)
+ * rows with a class outside [0, r) get zeros.  One launch instead of a sum, a scale and a row gather. */
+int tfc_fctp_class_rows(const float* part, int32_t n_parts, int32_t r, int32_t d_a, const float* inv_count,
+                        const int64_t* cls, int64_t n_rows, float* da, tfc_stream_t stream);
+
 /* Channel-contiguous copy of feature rows, for the operands of the dense contractions above:
  * e3nn stores a block as [mul][2l+1] (eigenn feature layout, see the conventions at the top), which
  * gives the contraction index u of o3.Linear / FullyConnectedTensorProduct the stride 2l+1; block b

@@ -78,7 +78,41 @@ __global__ __launch_bounds__(256) void tfc_sum_parts_kernel(const float* __restr
     }
 }
 
+// da[n, v] = inv_count[cls[n]] * sum_i part[i, cls[n], v], i ascending
+__global__ __launch_bounds__(256) void tfc_class_rows_kernel(const float* __restrict__ part, int n_parts, int r, int d_a,
+                                                             const float* __restrict__ inv_count,
+                                                             const int64_t* __restrict__ cls, long n_rows,
+                                                             float* __restrict__ da) {
+    const long total = n_rows * (long)d_a;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long n = i / d_a;
+        const int v = (int)(i - n * d_a);
+        const long c = cls[n];
+        float s = 0.f;
+        if (c >= 0 && c < r) {
+            const float* p = part + c * d_a + v;
+            s = p[0];
+            for (int k = 1; k < n_parts; ++k) s += p[(long)k * r * d_a];
+            s *= inv_count[c];
+        }
+        da[i] = s;
+    }
+}
+
 }  // namespace
+
+extern "C" int tfc_fctp_class_rows(const float* part, int32_t n_parts, int32_t r, int32_t d_a, const float* inv_count,
+                                   const int64_t* cls, int64_t n_rows, float* da, tfc_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    TFC_REQUIRE(n_parts > 0 && r > 0 && d_a > 0 && n_rows >= 0, TFC_EINVAL, "tfc_fctp_class_rows: bad size");
+    if (n_rows == 0) return TFC_OK;
+    TFC_REQUIRE(part && inv_count && cls && da, TFC_EINVAL, "tfc_fctp_class_rows: null tensor");
+    const int grid = (int)std::min<long>((n_rows * (long)d_a + 255) / 256, 4096);
+    TfcProfScope prof("tfc_class_rows_kernel", stream);
+    tfc_class_rows_kernel<<<grid, 256, 0, stream>>>(part, n_parts, r, d_a, inv_count, cls, (long)n_rows, da);
+    TFC_LAUNCH_CHECK("tfc_class_rows_kernel");
+    return TFC_OK;
+}
 
 // internal (tfc_dense.cpp): ordered sum of n_parts slabs of numel floats
 int tfc_sum_parts(const float* part, int n_parts, long numel, float* out, hipStream_t stream) {

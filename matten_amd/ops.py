@@ -1305,8 +1305,8 @@ class AttrFactors(NamedTuple):
 
 
 def _class_structure(labels: torch.Tensor):
-    """(inv [N] dense class ids, rep [u] first row of each class, one-hot C [N, r], u, r) of an
-    integer labelling; one host sync (the number of classes)."""
+    """(inv [N] dense class ids, rep [u] first row of each class, one-hot C [N, r], u, r, 1 / class sizes [r]) of
+    an integer labelling; one host sync (the number of classes)."""
     n = labels.shape[0]
     uniq, inv = torch.unique(labels, return_inverse=True)  # sync
     u = int(uniq.numel())
@@ -1316,7 +1316,7 @@ def _class_structure(labels: torch.Tensor):
     rep.scatter_reduce_(0, inv, ar, reduce="amin")
     Cm = torch.zeros(n, r, dtype=torch.float32, device=labels.device)
     Cm[ar, inv] = 1.0
-    return inv, rep, Cm, u, r
+    return inv, rep, Cm, u, r, 1.0 / Cm.sum(0).clamp_min(1.0)
 
 
 def attr_factors(a: torch.Tensor, classes: Optional[torch.Tensor] = None):
@@ -1343,7 +1343,7 @@ def attr_factors(a: torch.Tensor, classes: Optional[torch.Tensor] = None):
                 _ATTR_CLASSES.pop(next(iter(_ATTR_CLASSES)))
             hit = (classes, st)
             _ATTR_CLASSES[ckey] = hit
-        inv, rep, Cm, u, r = hit[1]
+        inv, rep, Cm, u, r, inv_count = hit[1]
         if 2 * r > d_a:
             return None
         key = (a.data_ptr(), a._version, tuple(a.shape), ckey)
@@ -1353,7 +1353,7 @@ def attr_factors(a: torch.Tensor, classes: Optional[torch.Tensor] = None):
         with torch.no_grad():
             R = torch.zeros(r, d_a, dtype=torch.float32, device=a.device)
             R[:u] = a.detach()[rep]
-        res = AttrFactors(Cm, R, inv, 1.0 / Cm.sum(0).clamp_min(1.0), True)
+        res = AttrFactors(Cm, R, inv, inv_count, True)  # (the class structure, sizes included, is cached per `classes`)
     else:
         key = (a.data_ptr(), a._version, tuple(a.shape), None)
         fhit = _ATTR_FACTORS.get(key)
@@ -1368,13 +1368,13 @@ def attr_factors(a: torch.Tensor, classes: Optional[torch.Tensor] = None):
                 coef = (torch.randint(1, 1 << 40, (d_a,), generator=gen, dtype=torch.int64) * 2 + 1).to(a.device)
                 _HASH_COEF[ck] = coef
             h = (a.detach().view(torch.int32).to(torch.int64) * coef).sum(dim=1)
-            inv, rep, Cm, u, r = _class_structure(h)
+            inv, rep, Cm, u, r, inv_count = _class_structure(h)
             if 2 * r <= d_a:
                 rows = a.detach()[rep]
                 if bool((rows[inv] == a.detach()).all().item()):  # sync; also rejects NaN rows
                     R = torch.zeros(r, d_a, dtype=torch.float32, device=a.device)
                     R[:u] = rows
-                    res = AttrFactors(Cm, R, inv, 1.0 / Cm.sum(0).clamp_min(1.0), False)
+                    res = AttrFactors(Cm, R, inv, inv_count, False)
     if len(_ATTR_FACTORS) >= 8:
         _ATTR_FACTORS.pop(next(iter(_ATTR_FACTORS)))
     _ATTR_FACTORS[key] = (a, res)
@@ -1500,8 +1500,9 @@ class _FctpFn(torch.autograd.Function):
                     )
                     for i, ((xo, mu, ao, mv, oo, mw, d, wo, alpha), lo) in enumerate(zip(spec.instructions, ctx.low))
                 ])
-                d_rows = (part.sum(dim=0) if ni > 1 else part[0]) * ctx.factors.inv_count[:, None]
-                da = d_rows[ctx.factors.inv]
+                da = torch.empty(n, spec.d_a, dtype=torch.float32, device=x.device)
+                _lib.check(_lib.lib().tfc_fctp_class_rows(_ptr(part), ni, r, spec.d_a, _ptr(ctx.factors.inv_count),
+                                                          _ptr(ctx.factors.inv), n, _ptr(da), _stream()))
         return dx, da, dw, None, (g if ctx.has_base else None), None
 
 

@@ -1072,3 +1072,25 @@ def test_gate_channel_contiguous_copies(device):
     bad = (_lib.IrBlock * 1)()
     bad[0].off, bad[0].mul, bad[0].dim = spec.d_out - 2, 2, 3
     assert L.tfc_gate_fwd_t(spec.c_array(), len(spec.segs), P(x), n, spec.d_in, spec.d_out, P(out), bad, 1, P(out_t), st) < 0
+
+
+def test_fctp_class_rows_entry_point(device):
+    """tfc_fctp_class_rows: da[n] = inv_count[cls[n]] * sum_i part[i, cls[n]], bit-exact against the same sum in
+    torch (ascending i); classes outside [0, r) give zero rows."""
+    from matten_amd import _lib, ops
+
+    g = torch.Generator().manual_seed(80)
+    ni, r, d_a, n = 3, 4, 24, 333
+    part = torch.randn(ni, r, d_a, generator=g).to(device)
+    inv_count = (1.0 / torch.randint(1, 90, (r,), generator=g).float()).to(device)
+    cls = torch.randint(0, r, (n,), generator=g).to(device)
+    cls[5] = r  # outside
+    cls[6] = -1
+    da = torch.full((n, d_a), float("nan"), device=device)
+    _lib.check(_lib.lib().tfc_fctp_class_rows(ops._ptr(part), ni, r, d_a, ops._ptr(inv_count), ops._ptr(cls), n, ops._ptr(da), ops._stream()))
+    rows = ((part[0] + part[1]) + part[2]) * inv_count[:, None]
+    ref = rows[cls.clamp(0, r - 1)]
+    ref[5] = 0
+    ref[6] = 0
+    assert torch.equal(da, ref)
+    assert _lib.lib().tfc_fctp_class_rows(ops._ptr(part), 0, r, d_a, ops._ptr(inv_count), ops._ptr(cls), n, ops._ptr(da), ops._stream()) < 0
