@@ -82,20 +82,39 @@ struct tfc_conv_plan {
 // M pre-pass: M[e][j] for edge e (the caller's edge order) and M-row entry j.  One M serves the forward (edges
 // grouped by receiver) and the backward (grouped by sender): both kernels look a row up by edge id.
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void tfc_m_prepass_kernel(const float* __restrict__ y,
-                                                            const MEnt* __restrict__ ments,
-                                                            const float* __restrict__ cgm, long n_edges,
-                                                            int msz, int d_sh, float* __restrict__ M) {
-    const long total = n_edges * (long)msz;
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
-         i += (long)gridDim.x * blockDim.x) {
-        const long k = i / msz;
-        const int j = (int)(i - k * msz);
-        const MEnt me = ments[j];
-        const float* yr = y + k * d_sh + me.y_off;
-        float v = 0.f;
-        for (int m2 = 0; m2 < me.n2; ++m2) v = fmaf(cgm[me.cg_row + m2], yr[m2], v);
-        M[i] = v;
+// One thread per M-row entry j: its descriptor and Clebsch-Gordan coefficients are read once and stay in
+// registers; the workgroup then walks the edges in groups of EPB, whose harmonics it stages in LDS (one contiguous
+// read), and every thread writes its entry of each of those edges - consecutive lanes, consecutive addresses.
+// (The first version took one thread per (edge, j): a 64-bit division and 3 + 2 n2 loads for every element.)
+constexpr int M_EPB = 16;
+__global__ __launch_bounds__(1024) void tfc_m_prepass_kernel(const float* __restrict__ y,
+                                                             const MEnt* __restrict__ ments,
+                                                             const float* __restrict__ cgm, long n_edges,
+                                                             int msz, int d_sh, float* __restrict__ M) {
+    constexpr int MAXN2 = 2 * TFC_LMAX + 1;
+    extern __shared__ float ys[];  // [M_EPB][d_sh]
+    for (long e0 = (long)blockIdx.x * M_EPB; e0 < n_edges; e0 += (long)gridDim.x * M_EPB) {
+        __syncthreads();
+        for (int idx = threadIdx.x; idx < M_EPB * d_sh; idx += blockDim.x) {
+            const int ee = idx / d_sh, c = idx - ee * d_sh;
+            ys[idx] = e0 + ee < n_edges ? y[(e0 + ee) * d_sh + c] : 0.f;
+        }
+        __syncthreads();
+        for (int j = threadIdx.x; j < msz; j += blockDim.x) {
+            const MEnt me = ments[j];
+            float c[MAXN2];
+#pragma unroll
+            for (int m2 = 0; m2 < MAXN2; ++m2) c[m2] = m2 < me.n2 ? cgm[me.cg_row + m2] : 0.f;
+            float* Mj = M + e0 * msz + j;
+#pragma unroll 4
+            for (int ee = 0; ee < M_EPB; ++ee) {
+                float v = 0.f;
+#pragma unroll
+                for (int m2 = 0; m2 < MAXN2; ++m2)
+                    if (m2 < me.n2) v = fmaf(c[m2], ys[ee * d_sh + me.y_off + m2], v);
+                if (e0 + ee < n_edges) Mj[(long)ee * msz] = v;
+            }
+        }
     }
 }
 
@@ -859,7 +878,9 @@ extern "C" int tfc_conv_m_build(const tfc_conv_plan* pl, const float* y, int64_t
     if (n_edges == 0) return TFC_OK;
     TFC_REQUIRE(y && M, TFC_EINVAL, "tfc_conv_m_build: null tensor");
     TfcProfScope prof("tfc_m_prepass_kernel", stream);
-    tfc_m_prepass_kernel<<<grid_for(n_edges * (long)pl->msz, 256), 256, 0, stream>>>(
+    const int threads = std::min(1024, round_up(pl->msz, 64));
+    TFC_REQUIRE(pl->d_sh <= 1024, TFC_EUNSUPPORTED, "tfc_conv_m_build: %d edge-attribute columns (at most 1024)", pl->d_sh);
+    tfc_m_prepass_kernel<<<grid_for(n_edges, M_EPB, 4096), threads, sizeof(float) * M_EPB * pl->d_sh, stream>>>(
         y, pl->ments, pl->cgm, (long)n_edges, pl->msz, pl->d_sh, M);
     TFC_LAUNCH_CHECK("tfc_m_prepass_kernel");
     return TFC_OK;
