@@ -507,6 +507,21 @@ __device__ __forceinline__ void bwd_item(const float* __restrict__ x, const floa
         xv[m1] = xr[m1];
         gx[m1] = 0.f;
     }
+#ifndef TFC_BWD_NO_WARM
+    // Warm-up: the M blocks this wave reads through the scalar cache are touched exactly once per backward pass,
+    // so every group of edges would wait for a scalar miss to HBM with 3-4 waves per SIMD to hide it.  Lane j
+    // first touches every 128-byte line of the M row of edge j (all edges of the node at once through the vector
+    // path); the scalar loads below then find the rows in L2.
+    {
+        float t = 0.f;
+        for (int k0 = beg; k0 < end; k0 += 64) {
+            const int kk = k0 + lane < end ? k0 + lane : end - 1;
+            const float* mr = M + (size_t)eid[kk] * msz;
+            for (int o = 0; o < msz; o += 32) t += mr[o];
+        }
+        asm volatile("" ::"v"(t));
+    }
+#endif
     for (int gi = 0; gi < it.grp_count; ++gi) {
         const PathDev p = paths[grp_paths[it.grp_start + gi]];
 #define TFC_BWD_CASE(B, C)                                                                            \
