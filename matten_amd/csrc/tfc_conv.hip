@@ -137,7 +137,7 @@ __device__ __forceinline__ void fwd_edges(const float* __restrict__ xb, const fl
         const float* xr = xb + (size_t)s * d_in;
 #pragma unroll
         for (int m1 = 0; m1 < D1; ++m1) xv[j][m1] = xr[m1];
-        wv[j] = wb[(size_t)e * w_numel];
+        wv[j] = __builtin_nontemporal_load(&wb[(size_t)e * w_numel]);  // every weight is read once: streaming load
     }
 #pragma unroll
     for (int j = 0; j < UNR; ++j) {
@@ -435,7 +435,7 @@ __device__ __forceinline__ void bwd_path(const float* __restrict__ w, const floa
             const float* gr = gb + (size_t)d * d_out;
 #pragma unroll
             for (int m3 = 0; m3 < D3; ++m3) g[j][m3] = gr[m3];
-            wv[j] = wb[(size_t)e[j] * w_numel];
+            wv[j] = __builtin_nontemporal_load(&wb[(size_t)e[j] * w_numel]);  // every weight is read once
         }
         float q[NEED_DY ? V : 1];
         if (NEED_DY) {
@@ -458,7 +458,9 @@ __device__ __forceinline__ void bwd_path(const float* __restrict__ w, const floa
                 gw = fmaf(xv[m1], t, gw);
                 gx[m1] = fmaf(wj, t, gx[m1]);
             }
-            if (ok && active) dwb[(size_t)e[j] * w_numel] = gw;
+            // (written once, read much later by another kernel: streaming store, so that it does not push the
+            // gathered rows and the M rows out of L2)
+            if (ok && active) __builtin_nontemporal_store(gw, &dwb[(size_t)e[j] * w_numel]);
             if (NEED_DY) {
 #pragma unroll
                 for (int m2 = 0; m2 < D2; ++m2) {
