@@ -15,6 +15,10 @@
 
 #include <cstdlib>
 
+// the [E, W] weights are written once and read by another kernel later: streaming stores keep them from evicting the
+// weight tiles and activations this kernel re-reads (config 3: 2.83 -> 2.80 ms)
+#define TFC_MLP_OUT_STORE(dst, v) __builtin_nontemporal_store((v), &(dst))
+
 namespace {
 
 typedef float floatx16 __attribute__((ext_vector_type(16)));
@@ -229,14 +233,14 @@ __global__ __launch_bounds__(256, (NA == 1 ? 3 : 2)) void tfc_radial_mlp_fwd_ker
 #pragma unroll
                     for (int i = 0; i < NA; ++i)
 #pragma unroll
-                        for (int reg = 0; reg < 16; ++reg) ob[ooff[i][reg]] = alpha * acc[i][reg];
+                        for (int reg = 0; reg < 16; ++reg) TFC_MLP_OUT_STORE(ob[ooff[i][reg]], alpha * acc[i][reg]);
                 } else {
 #pragma unroll
                     for (int i = 0; i < NA; ++i)
 #pragma unroll
                         for (int reg = 0; reg < 16; ++reg) {
                             const long row = r0 + wm * 32 * NA + i * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * half;
-                            if (row < a.n_rows) ob[ooff[i][reg]] = alpha * acc[i][reg];
+                            if (row < a.n_rows) TFC_MLP_OUT_STORE(ob[ooff[i][reg]], alpha * acc[i][reg]);
                         }
                 }
             }
