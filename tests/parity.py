@@ -44,6 +44,18 @@ CONFIGS = {
     "c5_layer0": dict(emb=64, lmax=2, irreps="64x0o+64x0e+64x1o+64x1e+64x2o+64x2e", layers=1, hidden=64, nh=2, n=12, a=2.1, graphs=1,
                       low_rank=True),
     "c4": dict(emb=128, lmax=3, irreps="128x0o+128x0e+128x1o+128x1e+128x2o+128x2e+128x3o+128x3e", layers=2, hidden=64, nh=2, n=2, a=2.6, graphs=1),
+    # config 4 with all THREE layers: the third layer is the 64-path shape (W 8192, D_mid 37 888, two 64-channel
+    # chunks per path) that the 2-layer case above never reaches
+    "c4_l2": dict(emb=128, lmax=3, irreps="128x0o+128x0e+128x1o+128x1e+128x2o+128x2e+128x3o+128x3e", layers=3, hidden=64, nh=2, n=2, a=2.6, graphs=1),
+    # the benchmark's own config-3 cell (4^3 = 64 atoms, a = 2.5), two graphs, all three layers
+    "c3_cell": dict(emb=64, lmax=2, irreps="64x0o+64x0e+64x1o+64x1e+64x2o+64x2e", layers=3, hidden=64, nh=2, n=4, a=2.5, graphs=2,
+                    low_rank=True),
+    # config 4's model (3 layers) on a 64-atom cell of the benchmark's lattice constant: 1854 edges.  The fp64 oracle
+    # keeps ~14 MB per edge alive for autograd at these irreps (measured: 9.2 GB at 208 edges, 17.1 GB at 784), so this
+    # is ~32 GB of host memory; the benchmark's 216-atom graph (6.3 k edges) would need ~92 GB and is linked to this
+    # case by the batch / size independence properties of tests/test_gpu_properties.py instead
+    "c4_cell64": dict(emb=128, lmax=3, irreps="128x0o+128x0e+128x1o+128x1e+128x2o+128x2e+128x3o+128x3e", layers=3, hidden=64, nh=2, n=4,
+                      a=2.5, graphs=1, low_rank=True),
 }
 R_CUT = 5.0
 AVG_NEIGH = 28.0

@@ -9,7 +9,7 @@ from tests.parity import CONFIGS, run_layer_parity
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("config", ["smoke", "minimal", "lmax3", "c3", "c3_lowrank", "c3_lowrank_nohint", "norm_act", "c4", "c5_layer0"])
+@pytest.mark.parametrize("config", ["smoke", "minimal", "lmax3", "c3", "c3_lowrank", "c3_lowrank_nohint", "norm_act", "c4", "c5_layer0", "c4_l2", "c3_cell", "c4_cell64"])
 def test_stack_parity(device, config):
     from matten_amd import ops
 
