@@ -379,7 +379,7 @@ def main():
                 roof["fwd_plus_bwd"] = {"achieved": both, "frac": both / HBM_PEAK_GBS}
         mlp_flops, lin_flops = dense_flops(model, n_nodes, n_edges)
         dense = {
-            "radial_mlp": mfma_roofline(kern, mlp_flops, ["mlp_fused_fwd", "gemm_mlp_fwd", "gemm_mlp_dh", "gemm_mlp_dw"]),
+            "radial_mlp": mfma_roofline(kern, mlp_flops, ["mlp_fused_fwd", "mlp_fused_bwd", "gemm_mlp_fwd", "gemm_mlp_dh", "gemm_mlp_dw"]),
             "o3_linear": mfma_roofline(kern, lin_flops, ["gemm_linear_fwd", "gemm_linear_dx", "gemm_linear_dw"]),
         }
         cpu = None

@@ -7,10 +7,15 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <map>
 #include <vector>
 
 int tfc_sum_parts(const float* part, int n_parts, long numel, float* out, hipStream_t stream);  // tfc_layout.hip
+extern "C" int tfc_radial_mlp_bwd_chain_supported(int32_t n_layers, const int32_t* dims);              // tfc_mlp.hip
+int tfc_radial_mlp_bwd_chain(int64_t n_rows, int32_t n_layers, const int32_t* dims, const float* const* weights,
+                             float act_cst, const float* const* hidden, const float* gout, float* const* dhidden,
+                             float* dx, hipStream_t stream);
 
 namespace {
 
@@ -214,6 +219,16 @@ extern "C" int tfc_radial_mlp_bwd(const float* x, int64_t n_rows, int32_t n_laye
     // h_0 = x, h_i = hidden[i-1]; g_L = gout, g_i = dhidden[i-1] = (g_{i+1} W_i^T / sqrt(d_i)) * act'(h_i)
     std::vector<tfc_gemm_desc> dws;
     const float* g = gout;
+    // the whole chain of hidden gradients in one launch when the network fits the fused kernel (tfc_mlp.hip)
+    static const bool no_chain = getenv("TFC_MLP_BWD_FUSED") && atoi(getenv("TFC_MLP_BWD_FUSED")) == 0;
+    bool chain = !no_chain && tfc_radial_mlp_bwd_chain_supported(n_layers, dims) && ((uintptr_t)gout & 15) == 0 &&
+                 weights[n_layers - 1] && ((uintptr_t)weights[n_layers - 1] & 15) == 0;
+    for (int i = 0; chain && i < n_layers; ++i)
+        chain = weights[i] && (i + 1 == n_layers || (hidden[i] && dhidden[i]));
+    if (chain && (n_layers > 1 || dx)) {
+        int rc = tfc_radial_mlp_bwd_chain(E, n_layers, dims, weights, act_cst, hidden, gout, dhidden, dx, (hipStream_t)stream);
+        if (rc != TFC_OK) return rc;
+    }
     for (int i = n_layers - 1; i >= 0; --i) {
         const int hin = dims[i], hout = dims[i + 1];
         const float alpha = 1.f / std::sqrt((float)hin);
@@ -230,6 +245,10 @@ extern "C" int tfc_radial_mlp_bwd(const float* x, int64_t n_rows, int32_t n_laye
         if (!dh) {
             TFC_REQUIRE(i == 0, TFC_EINVAL, "tfc_radial_mlp_bwd: dhidden[%d] is null", i - 1);
             break;
+        }
+        if (chain) {  // already written by the fused kernel
+            g = dh;
+            continue;
         }
         tfc_gemm_desc d = desc(E, hin, hout, g, weights[i], dh, lin(hout), lin(1), lin(1), lin(hout), lin(hin), lin(1),
                                alpha, false, "gemm_mlp_dh");
