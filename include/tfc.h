@@ -377,6 +377,14 @@ int64_t tfc_gemm_workspace_floats(int64_t m, int64_t n, int64_t k);
 int tfc_radial_mlp_fwd(const float* x, int64_t n_rows, int32_t n_layers, const int32_t* dims,
                        const float* const* weights, float act_cst, float* const* hidden, float* out,
                        tfc_stream_t stream);
+/* The same call with caller scratch of tfc_radial_mlp_fwd_workspace_floats floats (16-byte aligned): the last layer
+ * - all but a few per cent of the network's arithmetic - then runs on v_mfma_f32_32x32x16_bf16 with every fp32 operand
+ * cut into three bf16 pieces that add up to it exactly (six piece products per product: fp32 accuracy, see
+ * csrc/tfc_mlp.hip), at 2.67 x the rate of the fp32 matrix instruction.  Null or short scratch: as tfc_radial_mlp_fwd. */
+int64_t tfc_radial_mlp_fwd_workspace_floats(int32_t n_layers, const int32_t* dims);
+int tfc_radial_mlp_fwd_ws(const float* x, int64_t n_rows, int32_t n_layers, const int32_t* dims,
+                          const float* const* weights, float act_cst, float* const* hidden, float* out,
+                          float* workspace, int64_t workspace_floats, tfc_stream_t stream);
 
 /* Backward of the radial FullyConnectedNet (what autograd derives from eigenn/nn/utils.py:247-252,262).
  * Arguments as for the forward; `hidden` are the forward's saved activations, `gout` [n_rows,

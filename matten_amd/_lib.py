@@ -146,6 +146,8 @@ SIGNATURES = {
     "tfc_gemm_group": (C.c_int, [C.POINTER(GemmDesc), _I32, _P]),
     "tfc_gemm_workspace_floats": (_I64, [_I64, _I64, _I64]),
     "tfc_radial_mlp_fwd": (C.c_int, [_P, _I64, _I32, C.POINTER(_I32), C.POINTER(_P), _F, C.POINTER(_P), _P, _P]),
+    "tfc_radial_mlp_fwd_workspace_floats": (_I64, [_I32, C.POINTER(_I32)]),
+    "tfc_radial_mlp_fwd_ws": (C.c_int, [_P, _I64, _I32, C.POINTER(_I32), C.POINTER(_P), _F, C.POINTER(_P), _P, _P, _I64, _P]),
     "tfc_radial_mlp_bwd_workspace_floats": (_I64, [_I64, _I32, C.POINTER(_I32)]),
     "tfc_radial_mlp_bwd": (C.c_int, [_P, _I64, _I32, C.POINTER(_I32), C.POINTER(_P), _F, C.POINTER(_P), _P, C.POINTER(_P), _P,
                                      C.POINTER(_P), _P, _I64, _P]),

@@ -17,7 +17,11 @@
 
 // the [E, W] weights are written once and read by another kernel later: streaming stores keep them from evicting the
 // weight tiles and activations this kernel re-reads (config 3: 2.83 -> 2.80 ms)
+#ifdef TFC_MLP_PLAIN_STORE
+#define TFC_MLP_OUT_STORE(dst, v) ((dst) = (v))
+#else
 #define TFC_MLP_OUT_STORE(dst, v) __builtin_nontemporal_store((v), &(dst))
+#endif
 
 namespace {
 
@@ -28,9 +32,12 @@ constexpr int MAXL = 6;   // layers
 // NA = accumulator tiles (32 rows each) per wave: the workgroup owns RB = 64 * NA edges.  NA = 2
 // halves the number of times W_L is streamed from L2; NA = 1 doubles the number of workgroups and
 // lets three of them share a CU, which is what fills the chip when E / 128 is only a few hundred.
-template <int NA> struct Tile {
-    static constexpr int RB = 64 * NA;   // edges per workgroup
-    static constexpr int SA = RB + 4;    // LDS row stride of the activation tile [k][row]
+// WM = rows of waves (two waves side by side per row): 2 in the fp32 kernels (256 threads), 4 in the bf16-piece
+// kernel (512 threads, RB = 256).
+template <int NA, int WM = 2> struct Tile {
+    static constexpr int RB = 32 * NA * WM;  // edges per workgroup
+    static constexpr int SA = RB + 4;        // LDS row stride of the activation tile [k][row]
+    static constexpr int NT = 128 * WM;      // threads per workgroup
 };
 constexpr int SB = 64 + 4;  // LDS row stride of a weight tile [k][col]
 
@@ -55,12 +62,13 @@ __device__ __forceinline__ float ssp_act(float v, float cst) {
 }
 
 // stage a weight tile W[k0.., c0 .. c0+63] (row-major [K, ldw]) into LDS as [k][col], zero padded
+template <int NT = 256>
 __device__ __forceinline__ void stage_weights(const float* __restrict__ W, int K, int ldw, int c0, int ncols,
                                               float* __restrict__ Bs, int t) {
-    // 64 k x 16 column quads = 1024 float4: 4 per thread
+    // 64 k x 16 column quads = 1024 float4: 1024 / NT per thread
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const int c4 = t & 15, k = (t >> 4) + 16 * q;
+    for (int q = 0; q < 1024 / NT; ++q) {
+        const int c4 = t & 15, k = (t >> 4) + (NT / 16) * q;
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
         const int c = c0 + 4 * c4;
         if (k < K) {
@@ -77,32 +85,29 @@ __device__ __forceinline__ void stage_weights(const float* __restrict__ W, int K
     }
 }
 
-template <int NA>
-__global__ __launch_bounds__(256, (NA == 1 ? 3 : 2)) void tfc_radial_mlp_fwd_kernel(const MlpArgs a) {
-    constexpr int RB = Tile<NA>::RB, SA = Tile<NA>::SA;
-    __shared__ __attribute__((aligned(16))) float act[64 * SA];     // current activations, [k][row]
-    __shared__ __attribute__((aligned(16))) float wt[2][64 * SB];   // weight tiles, [k][col]
-
-    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+// Input tile and hidden layers of the forward: on return act holds the last hidden activations of the
+// workgroup's RB edges, [k][row] with k < 64 (zero beyond the layer's width), and every wave has passed the
+// barrier that follows their last write.
+template <int NA, int WM = 2>
+__device__ __forceinline__ void mlp_hidden_forward(const MlpArgs& a, float* __restrict__ act, float* __restrict__ wt0,
+                                                   const int t, const long r0, const bool full_rows) {
+    constexpr int RB = Tile<NA, WM>::RB, SA = Tile<NA, WM>::SA, NT = Tile<NA, WM>::NT;
+    const int lane = t & 63, wave = t >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int half = lane >> 5, l31 = lane & 31;
-    const long r0 = (long)blockIdx.x * RB;
-
     // input tile, k-major (rows past the end re-read the last row; nothing of them is stored)
     {
         const int d0 = a.dims[0];
-        for (int i = t; i < RB * 64; i += 256) {
+        for (int i = t; i < RB * 64; i += NT) {
             const int row = i / 64, k = i - row * 64;
             long r = r0 + row;
             r = r < a.n_rows ? r : a.n_rows - 1;
             act[k * SA + row] = k < d0 ? a.x[r * d0 + k] : 0.f;
         }
     }
-    const bool full_rows = r0 + RB <= a.n_rows;  // no row of this workgroup lies past the end
-    // hidden layers
     for (int l = 0; l + 1 < a.n_layers; ++l) {
         const int din = a.dims[l], dout = a.dims[l + 1];
-        stage_weights(a.w[l], din, dout, 0, dout, wt[0], t);
+        stage_weights<NT>(a.w[l], din, dout, 0, dout, wt0, t);
         __syncthreads();
         floatx16 acc[NA];
 #pragma unroll
@@ -111,7 +116,7 @@ __global__ __launch_bounds__(256, (NA == 1 ? 3 : 2)) void tfc_radial_mlp_fwd_ker
             for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
         const int kp = (din + 1) >> 1;  // k pairs (an odd width reads one zero row of padding)
         for (int s = 0; s < kp; ++s) {
-            const float b = wt[0][(2 * s + half) * SB + wn * 32 + l31];
+            const float b = wt0[(2 * s + half) * SB + wn * 32 + l31];
 #pragma unroll
             for (int i = 0; i < NA; ++i) {
                 const float av = act[(2 * s + half) * SA + wm * 32 * NA + 32 * i + l31];
@@ -151,6 +156,20 @@ __global__ __launch_bounds__(256, (NA == 1 ? 3 : 2)) void tfc_radial_mlp_fwd_ker
         }
         __syncthreads();
     }
+}
+
+template <int NA>
+__global__ __launch_bounds__(256, (NA == 1 ? 3 : 2)) void tfc_radial_mlp_fwd_kernel(const MlpArgs a) {
+    constexpr int RB = Tile<NA>::RB, SA = Tile<NA>::SA;
+    __shared__ __attribute__((aligned(16))) float act[64 * SA];     // current activations, [k][row]
+    __shared__ __attribute__((aligned(16))) float wt[2][64 * SB];   // weight tiles, [k][col]
+
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int half = lane >> 5, l31 = lane & 31;
+    const long r0 = (long)blockIdx.x * RB;
+    const bool full_rows = r0 + RB <= a.n_rows;  // no row of this workgroup lies past the end
+    mlp_hidden_forward<NA>(a, act, wt[0], t, r0, full_rows);
     // last layer: stream W_L in 64-column tiles, the activation tile stays in LDS
     {
         const int L = a.n_layers - 1;
@@ -250,6 +269,235 @@ __global__ __launch_bounds__(256, (NA == 1 ? 3 : 2)) void tfc_radial_mlp_fwd_ker
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// fp32 products on the bf16 matrix instruction (v_mfma_f32_32x32x16_bf16, 16 x the rate of the fp32 form).
+//
+// A float is cut into three bf16 pieces, x = h + m + l: h = x truncated to its upper 16 bits (never overflows),
+// m = bf16(x - h), l = bf16(x - h - m), round to nearest.  x - h and x - h - m are exact in fp32 and the last
+// remainder has at most 8 significant bits, so the three pieces add up to x EXACTLY.  A product a b is then the sum
+// of nine piece products, each exact in the fp32 accumulator of the instruction; the three smallest (m l, l m, l l:
+// below 2^-24 |a b|) are dropped, the other six are accumulated - the five small ones into an accumulator of their
+// own, added to the h h sum at the end.  Measured against fp64 (tools/selftest/bf16x3_probe.hip, K = 16 .. 65536,
+// normal operands): max error / sum |a b| = 0.6 - 0.9e-7, against 1.6 - 2.2e-7 for the fmaf chain of
+// v_mfma_f32_32x32x2_f32 - no precision is given up.  Six instructions of 32 cycles contract K = 16 where the fp32
+// form needs eight of 64 cycles: 2.67 x the fp32 matrix rate, which moves these products from the matrix cores'
+// roofline to HBM's (their [E, W] operand).
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned uintx4 __attribute__((ext_vector_type(4)));
+typedef float floatx2 __attribute__((ext_vector_type(2)));
+
+struct Pieces8 {  // eight consecutive k of one row / column, as MFMA operand fragments
+    uintx4 h, m, l;
+};
+
+__device__ __forceinline__ Pieces8 split8(const float* x) {
+    Pieces8 r;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const unsigned u0 = __float_as_uint(x[2 * p]), u1 = __float_as_uint(x[2 * p + 1]);
+        r.h[p] = __builtin_amdgcn_perm(u1, u0, 0x07060302u);  // (u1 & 0xffff0000) | (u0 >> 16)
+        const float a0 = x[2 * p] - __uint_as_float(u0 & 0xffff0000u);
+        const float a1 = x[2 * p + 1] - __uint_as_float(u1 & 0xffff0000u);
+        const bf16x2 mm = {(__bf16)a0, (__bf16)a1};
+        const unsigned mu = __builtin_bit_cast(unsigned, mm);
+        r.m[p] = mu;
+        const float b0 = a0 - __uint_as_float(mu << 16);
+        const float b1 = a1 - __uint_as_float(mu & 0xffff0000u);
+        const bf16x2 ll = {(__bf16)b0, (__bf16)b1};
+        r.l[p] = __builtin_bit_cast(unsigned, ll);
+    }
+    return r;
+}
+
+// acc += a_h b_h ; lo += the five next terms (smallest first)
+__device__ __forceinline__ void mfma_x3(const Pieces8& a, const Pieces8& b, floatx16& acc, floatx16& lo) {
+    const bf16x8 ah = __builtin_bit_cast(bf16x8, a.h), am = __builtin_bit_cast(bf16x8, a.m), al = __builtin_bit_cast(bf16x8, a.l);
+    const bf16x8 bh = __builtin_bit_cast(bf16x8, b.h), bm = __builtin_bit_cast(bf16x8, b.m), bl = __builtin_bit_cast(bf16x8, b.l);
+    lo = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, lo, 0, 0, 0);
+    lo = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, lo, 0, 0, 0);
+    lo = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bm, lo, 0, 0, 0);
+    lo = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bm, lo, 0, 0, 0);
+    lo = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bh, lo, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc, 0, 0, 0);
+}
+
+// LDS image of an operand tile as pieces: three planes [h | m | l], each [row or column][64 k] bf16 with k contiguous
+// and a row stride of 144 bytes (9 sixteen-byte units: ds_read_b128 / ds_write_b128 of consecutive rows are free of
+// bank conflicts).
+constexpr int X3_ROW = 72;                 // bf16 per row (64 + 8 pad)
+constexpr int X3_PLANE64 = 64 * X3_ROW;    // bf16 per plane of a 64-row tile
+
+__device__ __forceinline__ void x3_store(__bf16* tile, int plane_elems, int row, int k0, const Pieces8& p) {
+    *reinterpret_cast<uintx4*>(tile + row * X3_ROW + k0) = p.h;
+    *reinterpret_cast<uintx4*>(tile + plane_elems + row * X3_ROW + k0) = p.m;
+    *reinterpret_cast<uintx4*>(tile + 2 * plane_elems + row * X3_ROW + k0) = p.l;
+}
+__device__ __forceinline__ Pieces8 x3_load(const __bf16* tile, int plane_elems, int row, int k0) {
+    Pieces8 p;
+    p.h = *reinterpret_cast<const uintx4*>(tile + row * X3_ROW + k0);
+    p.m = *reinterpret_cast<const uintx4*>(tile + plane_elems + row * X3_ROW + k0);
+    p.l = *reinterpret_cast<const uintx4*>(tile + 2 * plane_elems + row * X3_ROW + k0);
+    return p;
+}
+
+constexpr int X3_TILE = 3 * X3_PLANE64;         // bf16 per 64-row tile image (27 648 bytes)
+constexpr int X3_TILE_VEC = X3_TILE * 2 / 16;    // 16-byte units per image
+
+// Pre-pass: a weight matrix cut into pieces and laid out as the LDS images the product kernels copy in, one
+// contiguous image per 64-wide tile:  img[tile][plane][r][k] = piece(src[tile * 64 * (on_r ? rs : ks) + r rs + k ks]).
+// The kernels that stream the matrix then read consecutive memory (the rows of the matrix itself lie W floats apart,
+// and at W = 8192 every row of a tile sits on the same L2 channel: 1564 workgroups fetching their copies of a tile
+// took three times as long as the products on it), and nobody repeats the cutting.
+__global__ __launch_bounds__(256) void tfc_x3_pack_kernel(const float* __restrict__ src, __bf16* __restrict__ img, int ntiles,
+                                                           long rs, long ks, int r_lim, int k_lim, int on_r) {
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    const int tile = (int)(idx >> 9);
+    if (tile >= ntiles) return;
+    const int in = (int)(idx & 511);
+    const int r = on_r ? (in & 63) : (in >> 3), o = on_r ? (in >> 6) : (in & 7);
+    const int rr = (on_r ? tile * 64 : 0) + r, k0 = (on_r ? 0 : tile * 64) + 8 * o;
+    float x[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) x[j] = (rr < r_lim && k0 + j < k_lim) ? src[rr * rs + (long)(k0 + j) * ks] : 0.f;
+    // forward images (on_r): column c of the tile goes to image row (c >> 1) + 32 (c & 1), so that lane l of the kernel
+    // ends up with the adjacent columns 2 l and 2 l + 1 in its two accumulators and stores them as one 8-byte value
+    const int ir = on_r ? (r >> 1) + 32 * (r & 1) : r;
+    x3_store(img + (long)tile * X3_TILE, X3_PLANE64, ir, 8 * o, split8(x));
+}
+
+// Forward with the last layer on the bf16 instruction.  512 threads own 256 edges; the hidden layers as in
+// tfc_radial_mlp_fwd_kernel.  Then wave i keeps the pieces of its 32 rows of the last hidden activations (A operand,
+// K = 64) in registers for the rest of the kernel, and W_L goes by in 64-column tiles whose images the pre-pass made:
+// straight 16-byte copies into LDS (double buffered); a wave multiplies its rows with both 32-column halves of the
+// tile (24 matrix instructions each) and streams the results out.
+__global__ __launch_bounds__(512, 1) void tfc_radial_mlp_fwd_x3_kernel(const MlpArgs a, const uintx4* __restrict__ wimg) {
+    constexpr int NA = 2, WM = 4, RB = Tile<NA, WM>::RB, SA = Tile<NA, WM>::SA, NT = Tile<NA, WM>::NT;
+    constexpr int SMEM_FLOATS = 64 * SA + 64 * SB;
+    static_assert(2 * X3_TILE * 2 <= SMEM_FLOATS * 4, "the weight tiles reuse the hidden layers' LDS");
+    __shared__ __attribute__((aligned(16))) float smem[SMEM_FLOATS];
+    float* act = smem;
+    float* wt0 = smem + 64 * SA;
+
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int half = lane >> 5, l31 = lane & 31;
+    const long r0 = (long)blockIdx.x * RB;
+    const bool full_rows = r0 + RB <= a.n_rows;
+    mlp_hidden_forward<NA, WM>(a, act, wt0, t, r0, full_rows);
+
+    const int L = a.n_layers - 1;
+    const int din = a.dims[L], W = a.dims[L + 1];
+    const float alpha = 1.0f / sqrtf((float)din);
+    const int ntiles = (W + 63) / 64;
+
+    // this wave's rows of the activations as operand fragments: k step s, lane (row l31, half) holds k = 16 s + 8 half + j
+    Pieces8 A[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        float x[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) x[j] = act[(16 * s + 8 * half + j) * SA + 32 * wave + l31];
+        A[s] = split8(x);
+    }
+    __syncthreads();  // the activations are in registers: their LDS becomes the weight tiles
+    uintx4* tiles = reinterpret_cast<uintx4*>(smem);
+
+    constexpr int NQ = (X3_TILE_VEC + NT - 1) / NT;  // 16-byte units per thread and tile (the last one partly)
+    uintx4 pre[NQ];
+    auto request = [&](int n) {
+        const uintx4* __restrict__ src = wimg + (long)n * X3_TILE_VEC;
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            const int i = t + NT * q;
+            pre[q] = src[i < X3_TILE_VEC ? i : X3_TILE_VEC - 1];
+        }
+    };
+    auto stage = [&](int n) {
+        uintx4* dst = tiles + (n & 1) * X3_TILE_VEC;
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            const int i = t + NT * q;
+            if (q + 1 < NQ || i < X3_TILE_VEC) dst[i] = pre[q];
+        }
+    };
+    // Workgroups walk the tiles from different starting points.  They run in step, and rows of the output lie W floats
+    // apart: if all of them wrote column block n at the same time, the whole chip's stores (and its reads of the image)
+    // would land on the few memory channels that block maps to (W = 8192: a 32 KB stride).
+#ifdef TFC_X3_NOSTAGGER
+    const int first = 0;
+#else
+    const int first = (int)(blockIdx.x % (unsigned)ntiles);
+#endif
+    auto tile_of = [&](int i) { const int n = first + i; return n < ntiles ? n : n - ntiles; };
+    request(tile_of(0));
+    stage(0);
+    __syncthreads();
+    const long row_base = r0 + 32 * wave + 4 * half;  // + (reg & 3) + 8 (reg >> 2)
+    floatx2 outv[16];
+    float* __restrict__ prev_ob = a.out;
+    bool fast_prev = false;  // per lane: outv holds a tile that still has to be stored
+    for (int it = 0; it < ntiles; ++it) {
+        const bool more = it + 1 < ntiles;
+        const int n = tile_of(it);
+        if (more) request(tile_of(it + 1));
+        const __bf16* tile = reinterpret_cast<const __bf16*>(tiles + (it & 1) * X3_TILE_VEC);
+        // The results of a tile wait in registers and leave while the NEXT tile is multiplied, two stores behind every
+        // group of six matrix instructions: issued in one burst after the products they fill the store queue, the
+        // waves stall on it and the matrix cores idle until it drains (measured: products and stores added up).
+        floatx16 acc[2], lo[2];
+#pragma unroll
+        for (int n2 = 0; n2 < 2; ++n2) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[n2][r] = 0.f, lo[n2][r] = 0.f;
+            Pieces8 B[4];
+#pragma unroll
+            for (int s = 0; s < 4; ++s) B[s] = x3_load(tile, X3_PLANE64, 32 * n2 + l31, 16 * s + 8 * half);
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+#ifndef TFC_X3_NOMFMA
+                mfma_x3(A[s], B[s], acc[n2], lo[n2]);
+#else
+                acc[n2][s] += __uint_as_float(B[s].h[0] ^ A[s].h[1]), lo[n2][s] += __uint_as_float(B[s].m[1] ^ B[s].l[2]);
+#endif
+                if (fast_prev) {
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) {
+                        const int reg = 2 * (4 * n2 + s) + q;
+                        const int dr = (reg & 3) + 8 * (reg >> 2);
+#ifdef TFC_X3_NOSTORE
+                        if (outv[reg].x == 12345.678f)
+#endif
+                        TFC_MLP_OUT_STORE(*reinterpret_cast<floatx2*>(prev_ob + (long)dr * W), outv[reg]);
+                    }
+                }
+            }
+        }
+        // lane l31 holds columns 2 l31 (accumulator 0) and 2 l31 + 1 (accumulator 1) of the tile: 256 contiguous
+        // bytes per row and half wave
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) outv[reg] = floatx2{alpha * (acc[0][reg] + lo[0][reg]), alpha * (acc[1][reg] + lo[1][reg])};
+        const int c = n * 64 + 2 * l31;
+        prev_ob = a.out + row_base * W + (c < W ? c : 0);
+        fast_prev = full_rows && c < W;
+        if (!full_rows && c < W) {  // the workgroup with rows past the end: checked stores, right away
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+                const int dr = (reg & 3) + 8 * (reg >> 2);
+                if (row_base + dr < a.n_rows) TFC_MLP_OUT_STORE(*reinterpret_cast<floatx2*>(prev_ob + (long)dr * W), outv[reg]);
+            }
+        }
+        if (more) stage(it + 1);
+        __syncthreads();
+    }
+    if (fast_prev) {
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) {
+            const int dr = (reg & 3) + 8 * (reg >> 2);
+            TFC_MLP_OUT_STORE(*reinterpret_cast<floatx2*>(prev_ob + (long)dr * W), outv[reg]);
+        }
+    }
+}
 
 // ---------------------------------------------------------------------------------------------
 // Fused backward of the hidden chain (what autograd derives from eigenn/nn/utils.py:247-252,262):
@@ -460,9 +708,20 @@ __global__ __launch_bounds__(256, 2) void tfc_radial_mlp_bwd_kernel(const MlpBwd
 
 }  // namespace
 
+extern "C" int64_t tfc_radial_mlp_fwd_workspace_floats(int32_t n_layers, const int32_t* dims) {
+    if (!dims || n_layers < 1 || dims[n_layers] <= 0) return -1;
+    return (int64_t)((dims[n_layers] + 63) / 64) * (X3_TILE * 2 / 4);
+}
+
 extern "C" int tfc_radial_mlp_fwd(const float* x, int64_t n_rows, int32_t n_layers, const int32_t* dims,
                                   const float* const* weights, float act_cst, float* const* hidden, float* out,
-                                  tfc_stream_t stream_) {
+                                  tfc_stream_t stream) {
+    return tfc_radial_mlp_fwd_ws(x, n_rows, n_layers, dims, weights, act_cst, hidden, out, nullptr, 0, stream);
+}
+
+extern "C" int tfc_radial_mlp_fwd_ws(const float* x, int64_t n_rows, int32_t n_layers, const int32_t* dims,
+                                     const float* const* weights, float act_cst, float* const* hidden, float* out,
+                                     float* workspace, int64_t workspace_floats, tfc_stream_t stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     TFC_REQUIRE(n_rows >= 0, TFC_EINVAL, "tfc_radial_mlp_fwd: negative row count");
     TFC_REQUIRE(dims && weights && hidden, TFC_EINVAL, "tfc_radial_mlp_fwd: null table");
@@ -506,6 +765,20 @@ extern "C" int tfc_radial_mlp_fwd(const float* x, int64_t n_rows, int32_t n_laye
     const long nb = (n_rows + rb - 1) / rb;
     TFC_REQUIRE(nb < (1LL << 31), TFC_EUNSUPPORTED, "tfc_radial_mlp_fwd: grid too large");
     TfcProfScope prof("mlp_fused_fwd", stream);
+    // the last layer on the bf16 matrix instruction (three-piece operands, see split8) when the caller brought the
+    // scratch for the images of W_L; TFC_MLP_X3=0 keeps the fp32 form
+    static const bool x3 = !(getenv("TFC_MLP_X3") && atoi(getenv("TFC_MLP_X3")) == 0);
+    const int64_t need = tfc_radial_mlp_fwd_workspace_floats(n_layers, dims);
+    if (x3 && workspace && workspace_floats >= need && ((uintptr_t)workspace & 15) == 0) {
+        const int L = n_layers - 1, W = dims[n_layers], ntiles = (W + 63) / 64;
+        tfc_x3_pack_kernel<<<(unsigned)((ntiles * 512 + 255) / 256), 256, 0, stream>>>(
+            weights[L], reinterpret_cast<__bf16*>(workspace), ntiles, 1, W, W, dims[L], 1);
+        TFC_LAUNCH_CHECK("tfc_x3_pack_kernel");
+        const long nbx = (n_rows + 255) / 256;
+        tfc_radial_mlp_fwd_x3_kernel<<<(unsigned)nbx, 512, 0, stream>>>(a, reinterpret_cast<const uintx4*>(workspace));
+        TFC_LAUNCH_CHECK("tfc_radial_mlp_fwd_x3_kernel");
+        return TFC_OK;
+    }
     if (small)
         tfc_radial_mlp_fwd_kernel<1><<<(unsigned)nb, 256, 0, stream>>>(a);
     else

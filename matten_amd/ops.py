@@ -1092,7 +1092,10 @@ def _radial_mlp_run(x, ws, act_cst: float):
         c_dims = (C.c_int32 * (nl + 1))(*dims)
         c_w = (C.c_void_p * nl)(*[w.data_ptr() for w in ws])
         c_h = (C.c_void_p * nl)(*([o.data_ptr() for o in outs[:-1]] + [None]))
-        _lib.check(_lib.lib().tfc_radial_mlp_fwd(_ptr(x), E, nl, c_dims, c_w, float(act_cst), c_h, _ptr(outs[-1]), _stream()))
+        need = int(_lib.lib().tfc_radial_mlp_fwd_workspace_floats(nl, c_dims))
+        wsp = _gemm_workspace(need)  # images of W_L for the bf16-piece kernel
+        _lib.check(_lib.lib().tfc_radial_mlp_fwd_ws(_ptr(x), E, nl, c_dims, c_w, float(act_cst), c_h, _ptr(outs[-1]), _ptr(wsp),
+                                                    wsp.numel(), _stream()))
         hs += outs
     else:
         for i, w in enumerate(ws):
