@@ -97,3 +97,23 @@ def collate_gpu(graphs: Sequence[Dict[str, np.ndarray]], r_cut: float, device) -
     out["ptr"] = nl["ptr"]
     out["edge_ordering"] = nl["ordering"]  # keeps the registered ordering alive with the batch
     return out
+
+
+def pad_null_edges(batch: Dict[str, torch.Tensor], n_edges: int, k: int = 1000) -> Dict[str, torch.Tensor]:
+    """The batch with its edge list padded to `n_edges` entries by NULL edges: node 0 -> node 0 across `k` cells, i.e.
+    far beyond any cutoff.  Their radial embedding is exactly zero (the cutoff polynomial is multiplied by r < r_max,
+    eigenn/nn/_nequip.py:69-78), hence - the radial network has no bias and ssp(0) = 0 - so are their tensor-product
+    weights, messages and every gradient through them: energies, forces and parameter gradients are those of the
+    unpadded batch, while all batches of a padded stream share one shape (matten_amd.graphs.GraphedStep)."""
+    ei, sh = batch[K.EDGE_INDEX], batch[K.EDGE_CELL_SHIFT]
+    e = int(ei.shape[1])
+    if n_edges < e:
+        raise ValueError(f"pad_null_edges: the batch has {e} edges, more than {n_edges}")
+    out = dict(batch)
+    pad = n_edges - e
+    if pad:
+        out[K.EDGE_INDEX] = torch.cat([ei, torch.zeros(2, pad, dtype=ei.dtype, device=ei.device)], dim=1)
+        far = torch.zeros(pad, 3, dtype=sh.dtype, device=sh.device)
+        far[:, 0] = k
+        out[K.EDGE_CELL_SHIFT] = torch.cat([sh, far], dim=0)
+    return out

@@ -1,5 +1,5 @@
 """HIP-graph replay of a whole step (forward, backward, gradient accumulation) for callers whose batch
-shape does not change between steps: molecular dynamics on one cell, repeated evaluation of one batch,
+SHAPE does not change between steps: molecular dynamics on one cell, repeated evaluation of one batch,
 training with padded / bucketed batches.
 
 A step of the hot path is ~170 short launches on two streams; issued one by one from Python the host needs
@@ -9,22 +9,38 @@ stream's fork and join included) the step replays with a single host call.  The 
 (its step is Lightning's eager loop, eigenn/model/model.py:239-327).
 
 Rules for the captured function: inputs and outputs live in tensors that keep their addresses (copy new
-values into them between replays), no host synchronisation inside (`.item()`, data-dependent shapes), and
-every cache the layers keep must be warm - GraphedStep runs the function a few times eagerly first.
+values into them between replays), no host synchronisation inside (`.item()`, data-dependent shapes).
+
+What may change between replays depends on `rebuild_topology`:
+
+* False (default): the edge orderings, the M-matrix layout and the class structure of the node attributes are
+  built during the eager warm-up and are NOT part of the graph.  Only positions, cell, shifts' values and
+  parameters may be updated in place; the tensors named in `static_topology` (edge_index, batch, species /
+  node-attribute classes ...) must not be written to - GraphedStep remembers their versions and raises on the
+  next call if one has changed (a replay would pair the new edge_index with the old orderings, silently).
+* True: the caches are dropped right before the capture, so the topology work (tfc_csr_build for both
+  groupings, the class table) is captured with the step and every replay redoes it from the CURRENT contents
+  of the static tensors: a new batch of the same shape (same N, same padded E, same number of graphs) is
+  taken by copy-in.  Requirements: the node-attribute classes come with their count (SpeciesEmbedding sets
+  it; ops._class_structure_static) so that no step of it synchronises, and padded edges are null edges
+  (longer than the cutoff: their radial embedding, weights, messages and gradients are exactly zero).
+  Edge-index validation does not run inside a replay.
 """
 from __future__ import annotations
 
-from typing import Callable
+from typing import Callable, Optional, Sequence
 
 import torch
 
 
 class GraphedStep:
-    def __init__(self, fn: Callable[[], object], warmup: int = 3):
+    def __init__(self, fn: Callable[[], object], warmup: int = 3, static_topology: Optional[Sequence[torch.Tensor]] = None,
+                 rebuild_topology: bool = False):
         from . import ops
         from .nn import point_conv
 
         self.fn = fn
+        self.rebuild_topology = bool(rebuild_topology)
         ops.clear_caches()  # (also synchronises the device)
         point_conv.reset_prefetch_state()
         cur = torch.cuda.current_stream()
@@ -35,15 +51,31 @@ class GraphedStep:
         quiet = getattr(torch.autograd.graph, "set_warn_on_accumulate_grad_stream_mismatch", None)
         if quiet is not None:
             quiet(False)
-        with torch.cuda.stream(s):  # torch asks for the warm-up on a non-default stream
-            for _ in range(warmup):
-                fn()
-        cur.wait_stream(s)
-        torch.cuda.synchronize()
-        self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
-            self.out = fn()
+        try:
+            with torch.cuda.stream(s):  # torch asks for the warm-up on a non-default stream
+                for _ in range(warmup):
+                    fn()
+            cur.wait_stream(s)
+            torch.cuda.synchronize()
+            if self.rebuild_topology:
+                # every topology cache misses inside the capture: its kernels become part of the graph
+                ops.clear_caches()
+            self.graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph):
+                self.out = fn()
+        finally:
+            if quiet is not None:
+                quiet(True)  # the diagnostic is on by default: give it back to unrelated code
+        self._static = [(t, t._version) for t in (static_topology or ())]
 
     def __call__(self):
+        if not self.rebuild_topology:
+            for t, v in self._static:
+                if t._version != v:
+                    raise RuntimeError(
+                        "GraphedStep: a topology tensor (edge_index / batch / species ...) was modified after the capture; the "
+                        "graph would replay with the orderings of the old one.  Capture with rebuild_topology=True to take new "
+                        "batches by copy-in, or build a new GraphedStep."
+                    )
         self.graph.replay()
         return self.out

@@ -65,6 +65,7 @@ class ConvStack(torch.nn.Module):
         # the attributes are an embedding of the species: tell the layers their classes (an
         # extension the oracle's layers ignore)
         if self.classes_hint:
+            data["species_index"].tfc_num_classes = int(w.shape[0])
             data[K.NODE_ATTRS_CLASSES] = data["species_index"]
         data = self.spharm_edges(data)
         data = self.radial_basis(data)

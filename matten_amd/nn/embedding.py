@@ -80,5 +80,6 @@ class SpeciesEmbedding(ModuleIrreps, torch.nn.Module):
         for k in self.out_fields:
             data[k] = embed
         if DataKey.NODE_ATTRS in self.out_fields:
+            idx.tfc_num_classes = int(w.shape[0])  # lets the self connection lay out the classes without a host sync
             data[DataKey.NODE_ATTRS_CLASSES] = idx
         return data

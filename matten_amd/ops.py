@@ -74,7 +74,9 @@ class EdgeOrdering:
             raise ValueError(f"edge_index must have shape [2, E], got {tuple(edge_index.shape)}")
         if not edge_index.is_cuda:
             raise RuntimeError("matten_amd: edge_index must live on a ROCm device (no CPU fallback exists)")
-        check_edge_orderings()  # the deferred verdict on earlier orderings (see below)
+        capturing = torch.cuda.is_current_stream_capturing()  # (graphs.GraphedStep(rebuild_topology=True))
+        if not capturing:
+            check_edge_orderings()  # the deferred verdict on earlier orderings (see below)
         ei = edge_index.to(torch.int64).contiguous()
         self.edge_index = ei
         self.n_nodes = int(n_nodes)
@@ -102,7 +104,9 @@ class EdgeOrdering:
         self._edge_rows = None
         self._m_cache = {}
         self._host_status = None
-        if VALIDATE_EDGES == "sync":
+        if capturing:
+            pass  # no host work inside a capture: the caller of a replayed step validates its batches itself (self.status)
+        elif VALIDATE_EDGES == "sync":
             self.validate()
         elif VALIDATE_EDGES == "deferred" and E:
             # the flag travels to pinned host memory behind the build; whoever builds the next ordering (or calls
@@ -1322,6 +1326,19 @@ def _class_structure(labels: torch.Tensor):
     return inv, rep, Cm, u, r, 1.0 / Cm.sum(0).clamp_min(1.0)
 
 
+def _class_structure_static(labels: torch.Tensor, u: int):
+    """_class_structure for labels known to lie in [0, u): no host synchronisation (classes without a member get a
+    zero row and weight 1)."""
+    n = labels.shape[0]
+    r = max(4, (u + 3) // 4 * 4)
+    ar = torch.arange(n, device=labels.device)
+    rep = torch.full((u,), n, dtype=torch.int64, device=labels.device)
+    rep.scatter_reduce_(0, labels, ar, reduce="amin")
+    Cm = torch.zeros(n, r, dtype=torch.float32, device=labels.device)
+    Cm[ar, labels] = 1.0
+    return labels, rep, Cm, u, r, 1.0 / Cm.sum(0).clamp_min(1.0)
+
+
 def attr_factors(a: torch.Tensor, classes: Optional[torch.Tensor] = None):
     """(C [N, r], R [r, d_a]) with a == C @ R exactly, when the rows of `a` are copies of a few distinct
     rows (node attributes that are a species embedding: eigenn/nn/embedding.py:59-75 sets NODE_ATTRS
@@ -1340,8 +1357,10 @@ def attr_factors(a: torch.Tensor, classes: Optional[torch.Tensor] = None):
         ckey = (classes.data_ptr(), classes._version, n)
         hit = _ATTR_CLASSES.get(ckey)
         if hit is None:
+            n_known = getattr(classes, "tfc_num_classes", None)  # set by whoever made the classes (SpeciesEmbedding)
             with torch.no_grad():
-                st = _class_structure(classes.reshape(-1).to(torch.int64))
+                lab = classes.reshape(-1).to(torch.int64)
+                st = _class_structure_static(lab, int(n_known)) if n_known else _class_structure(lab)
             if len(_ATTR_CLASSES) >= 8:
                 _ATTR_CLASSES.pop(next(iter(_ATTR_CLASSES)))
             hit = (classes, st)
@@ -1355,7 +1374,8 @@ def attr_factors(a: torch.Tensor, classes: Optional[torch.Tensor] = None):
             return fhit[1]
         with torch.no_grad():
             R = torch.zeros(r, d_a, dtype=torch.float32, device=a.device)
-            R[:u] = a.detach()[rep]
+            # (a class without a member has rep == n: its row stays zero)
+            R[:u] = a.detach()[rep.clamp_max(n - 1)] * (rep < n).to(a.dtype).unsqueeze(1)
         res = AttrFactors(Cm, R, inv, inv_count, True)  # (the class structure, sizes included, is cached per `classes`)
     else:
         key = (a.data_ptr(), a._version, tuple(a.shape), None)

@@ -50,3 +50,87 @@ def test_graph_replay_equals_eager_step(device):
         for a, b, c in zip([got[0], got[1]] + got[2], [ref[0], ref[1]] + ref[2], [got2[0], got2[1]] + got2[2]):
             assert torch.equal(a, b) and torch.equal(a, c)
         assert got[1].abs().max().item() > 0
+
+
+def test_replay_takes_new_batches_by_copy_in(device):
+    """rebuild_topology=True: the edge orderings and the class table are part of the graph, so a NEW batch of the same
+    (padded) shape copied into the static buffers replays to the bits of the eager step on it; padding by null edges
+    changes nothing (checked against the unpadded batch)."""
+    from matten_amd import keys as K
+    from matten_amd.data.crystal import pad_null_edges
+    from matten_amd.graphs import GraphedStep
+    from tests.parity import CONFIGS, Stack, _prep, make_batch
+
+    cfg = CONFIGS["minimal"]
+    torch.manual_seed(35)
+    raw = [make_batch(cfg, seed0=1000 + 100 * i) for i in range(3)]
+    for i, drop in ((1, 3), (2, 10)):  # (these small cells all have 624 edges: make the counts differ)
+        raw[i][K.EDGE_INDEX] = raw[i][K.EDGE_INDEX][:, :-drop].contiguous()
+        raw[i][K.EDGE_CELL_SHIFT] = raw[i][K.EDGE_CELL_SHIFT][:-drop].contiguous()
+    e_pad = max(int(b[K.EDGE_INDEX].shape[1]) for b in raw) + 7
+    assert len({int(b[K.EDGE_INDEX].shape[1]) for b in raw}) == 3
+    batches = [_prep(pad_null_edges(b, e_pad), str(device), torch.float32) for b in raw]
+    assert len({int(b[K.POSITIONS].shape[0]) for b in batches}) == 1
+    model = Stack("hip", cfg).to(device)
+    params = list(model.parameters())
+    n_graphs = cfg["graphs"]
+    static = {k: v.detach().clone() for k, v in batches[0].items()}  # the buffers the graph reads
+
+    def run(b):
+        for p in params:
+            p.grad = None
+        b = dict(b)
+        pos = b[K.POSITIONS].detach().requires_grad_(True)
+        b[K.POSITIONS] = pos
+        _, energy, _ = model(b, n_graphs)
+        energy.sum().backward()
+        return energy.detach(), pos.grad, [p.grad for p in params]
+
+    def snapshot(out):
+        return [out[0].clone(), out[1].clone()] + [g.clone() for g in out[2]]
+
+    # null edges are exactly null
+    ref_unpadded = snapshot(run(_prep(raw[1], str(device), torch.float32)))
+    ref_padded = snapshot(run(batches[1]))
+    for j, (a, b) in enumerate(zip(ref_unpadded, ref_padded)):
+        if j < 2:  # energy, forces: the null edges add exact zeros to the per-node sums
+            assert torch.equal(a, b), j
+        else:  # sums over all edges (weight gradients of the radial network) are cut into other ranges: rounding only
+            assert (a - b).abs().max().item() <= 2e-6 * max(b.abs().max().item(), 1e-30), j
+
+    replay = GraphedStep(lambda: run(static), rebuild_topology=True)
+    for i in (1, 2, 0, 2):
+        with torch.no_grad():
+            for k, v in batches[i].items():
+                static[k].copy_(v)
+        got = snapshot(replay())
+        ref = snapshot(run(batches[i]))
+        torch.cuda.synchronize()
+        for a, b in zip(got, ref):
+            assert torch.equal(a, b), i
+        assert got[1].abs().max().item() > 0
+
+
+def test_replay_refuses_a_changed_topology(device):
+    """Default mode: the orderings are not in the graph, so writing to a topology tensor must not replay silently."""
+    from matten_amd import keys as K
+    from matten_amd.graphs import GraphedStep
+    from tests.parity import CONFIGS, Stack, _prep, make_batch
+
+    cfg = CONFIGS["smoke"]
+    torch.manual_seed(35)
+    b0 = _prep(make_batch(cfg), str(device), torch.float32)
+    model = Stack("hip", cfg).to(device)
+
+    def step():
+        b = dict(b0)
+        b[K.POSITIONS] = b0[K.POSITIONS].detach()
+        with torch.no_grad():
+            return model(b, cfg["graphs"])[1]
+
+    replay = GraphedStep(step, static_topology=[b0[K.EDGE_INDEX], b0["species_index"]])
+    replay()
+    with torch.no_grad():
+        b0[K.EDGE_INDEX].copy_(b0[K.EDGE_INDEX].flip(0))
+    with pytest.raises(RuntimeError, match="topology"):
+        replay()
