@@ -14,6 +14,12 @@ gradient all-reduce over RCCL.  Work is data parallel over whole graphs, per-GPU
 edges pushed through a convolution layer (forward + backward) per second: "edge-layers/s"; the rate of
 batch edges through the whole 3-layer model is value / 3 (`model_edges_per_s`).
 
+Beside `ms_per_step` (one replay of the captured HIP graph on ONE static batch) the line carries what a training loop
+pays: `eager_ms_per_step` (the same batch, launch by launch from Python) and `fresh_batch_ms_per_step` (a NEW batch of the
+same padded shape every step, copied into the graph's static buffers, with the edge orderings, M matrices and class table
+rebuilt inside the replayed graph - what every Lightning step of the reference does, eigenn/model/model.py:279-327), plus
+`per_rank` (edges, step and all-reduce times of every rank) so that a scaling run explains itself.
+
 Also on the JSON line: `roofline` for the dominant kernel (tfc_conv_bwd_kernel; HBM-bound;
 algorithmic bytes per SURVEY.md §8d, duration from HIP events recorded by the library on the
 launch stream inside the timed region) and `cpu_baseline` (the CPU oracle = the reference's
@@ -100,12 +106,103 @@ def pmc_traffic(workload, kernel="tfc_conv_bwd_kernel"):
         return None, None
 
 
-def build_batch(wl, rank, device):
+def lib_hash():
+    """First 16 hex digits of the SHA-256 of the libtfc.so being timed (ties profiles and PMC files to a build)."""
+    import hashlib
+
+    from matten_amd import _lib
+
+    try:
+        with open(_lib.LIB_PATH, "rb") as f:
+            return hashlib.sha256(f.read()).hexdigest()[:16]
+    except OSError:
+        return None
+
+
+def fctp_flops(model, n_nodes):
+    """Algorithmic flops per step of the self connections: 2 sum mul_u mul_v mul_w (2l+1) per node
+    forward; x, weight and attribute gradients are three more products of that size."""
+    f = 0.0
+    for layer in model.convs:
+        sc = getattr(layer.update_fn, "self_connection", None)
+        if sc is not None:
+            f += 4 * 2.0 * n_nodes * sum(mu * mv * mw * d for _, mu, _, mv, _, mw, d, _, _ in sc.spec.instructions)
+    return f
+
+
+def pmc_traffic_hash(workload):
+    """The library hash recorded with the committed PMC file (None for files made before it was recorded)."""
+    import glob
+
+    hits = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", f"pmc_traffic_{workload}.json")))
+    if not hits:
+        return None
+    try:
+        with open(hits[-1]) as f:
+            return json.load(f).get("lib_sha256_16")
+    except Exception:
+        return None
+
+
+def fresh_batch_timing(args, wl, rank, device, batch0, compute, bucket, sync, dist):
+    """K steps, each on a batch the graph has not seen: three synthetic batches (other seeds) padded by null edges to one
+    edge count, copied in turn into static buffers; the captured step (rebuild_topology=True) redoes both edge groupings,
+    the M matrices and the class table from them.  Also the eager step on a fresh batch."""
+    from matten_amd import keys as K
+    from matten_amd.data.crystal import pad_null_edges
+    from matten_amd.graphs import GraphedStep
+
+    nb = 3
+    raws = [batch0] + [build_batch(wl, rank, device, seed_offset=7919 * (i + 1)) for i in range(nb - 1)]
+    edges = [int(b[K.EDGE_INDEX].shape[1]) for b in raws]
+    e_pad = (max(edges) + 63) // 64 * 64
+    if dist is not None:  # one shape on every rank is not needed (no edge exchange): each rank pads to its own maximum
+        pass
+    padded = [pad_null_edges(b, e_pad) for b in raws]
+    if len({int(b[K.POSITIONS].shape[0]) for b in padded}) != 1:
+        raise RuntimeError("fresh batches differ in their atom counts")
+    static = {k: v.detach().clone() for k, v in padded[0].items()}
+
+    def copy_in(i):
+        with torch.no_grad():
+            for k, v in padded[i % nb].items():
+                static[k].copy_(v)
+
+    replay = GraphedStep(lambda: compute(static), rebuild_topology=True)
+
+    def gstep(i):
+        copy_in(i)
+        g, grads = replay()
+        bucket.all_reduce_mean(grads=grads)
+
+    def estep(i):
+        copy_in(i)  # bumps the versions: every cache keyed on these tensors misses, as for a new batch
+        compute(static)
+        bucket.all_reduce_mean()
+
+    out = {"batches": nb, "edges": edges, "padded_edges": e_pad}
+    for name, fn in (("ms_per_step", gstep), ("eager_ms_per_step", estep)):
+        for i in range(2):
+            fn(i)
+        sync()
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            fn(i)
+        sync()
+        el = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=device)
+        if dist is not None:
+            dist.all_reduce(el, op=dist.ReduceOp.MAX)
+        out[name] = float(el.item()) / args.steps * 1e3
+    out["launch"] = "hip_graph_replay, topology rebuilt in the graph, batch copied in"
+    return out
+
+
+def build_batch(wl, rank, device, seed_offset=0):
     from matten_amd.data.crystal import synthetic_batch
     from matten_amd.harness import species_index
     from matten_amd import keys as K
 
-    batch, _ = synthetic_batch(wl["n"], wl["a"], wl["graphs"], seed0=1000 + rank * wl["graphs"], r_cut=R_CUT)
+    batch, _ = synthetic_batch(wl["n"], wl["a"], wl["graphs"], seed0=1000 + rank * wl["graphs"] + seed_offset, r_cut=R_CUT)
     batch["species_index"] = species_index(batch[K.ATOMIC_NUMBERS])
     batch = {k: v.to(device) for k, v in batch.items()}
     return batch
@@ -163,6 +260,11 @@ def main():
                     help="1 (default): the step (forward + backward into the flat gradient buffer) is captured once into a HIP graph "
                          "and every timed step is one replay of it (the gradient all-reduce stays outside the graph); 0: every step is "
                          "issued launch by launch from Python")
+    ap.add_argument("--fresh", type=int, default=1,
+                    help="1 (default): also time the step on a NEW batch every step (three synthetic batches of one padded shape, "
+                         "copied into the static buffers of a graph that rebuilds the edge orderings itself); 0: skip")
+    ap.add_argument("--graph-allreduce", type=int, default=0,
+                    help="1: try to capture the gradient all-reduce (RCCL) inside the HIP graph as well")
     ap.add_argument("--dist-single", action="store_true",
                     help="with --gpus 1: still initialise the process group (world size 1) and run the gradient all-reduce and the "
                          "MAX/SUM reductions through it, so that the RCCL path executes on a one-GPU box")
@@ -251,13 +353,16 @@ def main():
     pos0 = batch[K.POSITIONS]
     _SYNC_BEFORE_AR = bool(os.environ.get("TFC_SYNC_BEFORE_AR"))  # rehearsal aid
 
-    def compute():
+    def compute(src=None, reduce_inside=False):
+        src = batch if src is None else src
         bucket.zero()
-        b = dict(batch)
-        pos = pos0.detach().requires_grad_(True)
+        b = dict(src)
+        pos = src[K.POSITIONS].detach().requires_grad_(True)
         b[K.POSITIONS] = pos
         _, energy, _ = model(b, wl["graphs"])
         energy.sum().backward()
+        if reduce_inside:
+            bucket.all_reduce_mean()
         return pos.grad, [p.grad for p in params]  # (-forces, parameter gradients)
 
     def eager_step():
@@ -269,22 +374,39 @@ def main():
 
     step = eager_step
     mode = "eager"
+    ar_in_graph = False
     if args.graph and not args.overlap:
         # The batch shape is fixed, so the ~170 launches of a step are captured once and replayed: same kernels,
         # same arithmetic, same bits (tests/test_gpu_graph.py), no per-launch host work.
         from matten_amd.graphs import GraphedStep
 
-        try:
-            replay = GraphedStep(compute)
-        except Exception as ex:  # capture refused: keep the launch-by-launch step
-            print(f"bench.py: HIP-graph capture failed ({ex}); timing the eager step", file=sys.stderr)
-        else:
+        topo = [batch[K.EDGE_INDEX], batch[K.BATCH], batch["species_index"]]
+        replay = None
+        if args.graph_allreduce and dist is not None:
+            # the collective as a node of the graph: RCCL kernels captured like any other launch
+            try:
+                replay = GraphedStep(lambda: compute(reduce_inside=True), static_topology=topo)
+                ar_in_graph = True
+            except Exception as ex:
+                print(f"bench.py: capture with the all-reduce inside failed ({type(ex).__name__}: {ex}); capturing without it", file=sys.stderr)
+                ar_in_graph = f"failed: {type(ex).__name__}: {str(ex)[:200]}"
+                replay = None
+                torch.cuda.synchronize()
+        if replay is None:
+            try:
+                replay = GraphedStep(compute, static_topology=topo)
+            except Exception as ex:  # capture refused: keep the launch-by-launch step
+                print(f"bench.py: HIP-graph capture failed ({ex}); timing the eager step", file=sys.stderr)
+        if replay is not None:
             mode = "hip_graph_replay"
-
-            def step():
-                g, grads = replay()  # the tensors the captured step writes its gradients into
-                bucket.all_reduce_mean(grads=grads)
-                return g
+            if ar_in_graph is True:
+                def step():
+                    return replay()[0]
+            else:
+                def step():
+                    g, grads = replay()  # the tensors the captured step writes its gradients into
+                    bucket.all_reduce_mean(grads=grads)
+                    return g
 
     def sync():
         if dist is not None:
@@ -303,8 +425,30 @@ def main():
         step()
     sync()
     elapsed = time.perf_counter() - t0
+    own_elapsed = elapsed
     L.tfc_profile_enable(0)
     prof = _lib.profile_report()
+    # the same batch launch by launch (no event timers), as a training loop without graphs would issue it
+    eager_elapsed = None
+    if mode != "eager":
+        for _ in range(2):
+            eager_step()
+        sync()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            eager_step()
+        sync()
+        eager_elapsed = time.perf_counter() - t0
+    # the gradient all-reduce alone (pack + collective + divide), for the per-rank report
+    ar_ms = None
+    if dist is not None:
+        grads_now = [p.grad.clone() if p.grad is not None else None for p in params]
+        sync()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            bucket.all_reduce_mean(grads=grads_now)
+        torch.cuda.synchronize()
+        ar_ms = (time.perf_counter() - t0) / args.steps * 1e3
     if mode != "eager":
         # HIP events cannot be recorded between the nodes of a replayed graph, so the conv-kernel durations come from
         # K eager steps of the same work, right behind the timed replays (same process, same buffers); the rocprofv3
@@ -327,8 +471,33 @@ def main():
     prof_all = _lib.profile_report()
     L.tfc_profile_reset()
 
+    # a NEW batch every step
+    fresh = None
+    if args.fresh and args.graph and not args.overlap:
+        try:
+            fresh = fresh_batch_timing(args, wl, rank, device, batch, compute, bucket, sync, dist)
+        except Exception as ex:  # a report, never a reason to lose the headline number
+            import traceback
+
+            traceback.print_exc(file=sys.stderr)
+            fresh = {"error": f"{type(ex).__name__}: {str(ex)[:300]}"}
+            torch.cuda.synchronize()
+
     t = torch.tensor([elapsed], dtype=torch.float64, device=device)
     e = torch.tensor([float(n_edges)], dtype=torch.float64, device=device)
+    per_rank = None
+    if dist is not None:
+        mine = torch.tensor([float(n_edges), own_elapsed / args.steps * 1e3, ar_ms or 0.0,
+                             (eager_elapsed or 0.0) / args.steps * 1e3], dtype=torch.float64, device=device)
+        allr = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+        per_rank = [{"rank": i, "edges": int(v[0].item()), "step_ms": v[1].item(), "allreduce_ms": v[2].item(),
+                     "eager_step_ms": v[3].item() or None} for i, v in enumerate(allr)]
+    if eager_elapsed is not None:
+        te = torch.tensor([eager_elapsed], dtype=torch.float64, device=device)
+        if dist is not None:
+            dist.all_reduce(te, op=dist.ReduceOp.MAX)
+        eager_elapsed = float(te.item())
     if dist is not None:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dist.all_reduce(e, op=dist.ReduceOp.SUM)
@@ -365,7 +534,10 @@ def main():
             }
             # `frac` prices the ALGORITHMIC bytes (every operand as if read from HBM once); `traffic` is what the
             # counters saw reach HBM (gathered rows are served from L2 / Infinity Cache), `traffic_frac` its rate
+            roof["timing_source"] = ("HIP events recorded by the library inside the timed eager steps" if mode == "eager" else
+                                     "HIP events recorded by the library over the same number of eager steps right behind the timed replays")
             roof["traffic"], roof["traffic_source"] = pmc_traffic(args.workload)
+            roof["traffic_lib_sha256_16"] = pmc_traffic_hash(args.workload)
             roof["traffic_frac"] = roof["traffic"] / avg_s / 1e9 / HBM_PEAK_GBS if roof["traffic"] else None
             if "tfc_conv_fwd_kernel" in prof:
                 c2, tot2 = prof["tfc_conv_fwd_kernel"]
@@ -381,7 +553,15 @@ def main():
         dense = {
             "radial_mlp": mfma_roofline(kern, mlp_flops, ["mlp_fused_fwd", "mlp_fused_bwd", "gemm_mlp_fwd", "gemm_mlp_dh", "gemm_mlp_dw"]),
             "o3_linear": mfma_roofline(kern, lin_flops, ["gemm_linear_fwd", "gemm_linear_dx", "gemm_linear_dw"]),
+            # algorithmic (dense) flops of the self connection; the launches run its low-rank route over the distinct
+            # attribute rows, whose executed flops are emb / r times fewer - the figure prices the work asked for
+            "self_connection": mfma_roofline(kern, fctp_flops(model, n_nodes), ["gemm_fctp_fwd", "gemm_fctp_dx", "gemm_fctp_dw", "gemm_fctp_da",
+                                                                                  "gemm_fctp_lowrank_w", "gemm_fctp_da_rows", "tfc_class_rows_kernel"]),
         }
+        if dense["radial_mlp"]:
+            # the last layer of the forward runs on the bf16 instruction with three-piece operands (6 instructions of 32 cycles
+            # per K = 16 against 8 of 64): its own ceiling is 16 / 6 of the fp32 matrix peak
+            dense["radial_mlp"]["note"] = "peak = fp32 MFMA; the forward's last layer runs as bf16 x 3 pieces (ceiling 419 TFLOP/s fp32-equivalent)"
         cpu = None
         if world == 1 and not args.no_cpu_baseline:
             threads = min(16, os.cpu_count() or 1)
@@ -399,6 +579,9 @@ def main():
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": ms,
+            "eager_ms_per_step": None if eager_elapsed is None else eager_elapsed / args.steps * 1e3,
+            "fresh_batch": fresh,
+            "fresh_batch_ms_per_step": (fresh or {}).get("ms_per_step"),
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
@@ -417,6 +600,10 @@ def main():
                 "layer_shapes": shapes,
             },
             "roofline": roof,
+            "per_rank": per_rank,
+            "exposed_collective_ms": None if per_rank is None else max(r["allreduce_ms"] for r in per_rank),
+            "allreduce_in_graph": ar_in_graph,
+            "lib_sha256_16": lib_hash(),
             "mfma_roofline": dense,
             "cpu_baseline": cpu,
             "kernels": kern,

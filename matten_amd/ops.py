@@ -1334,8 +1334,8 @@ def _class_structure_static(labels: torch.Tensor, u: int):
     ar = torch.arange(n, device=labels.device)
     rep = torch.full((u,), n, dtype=torch.int64, device=labels.device)
     rep.scatter_reduce_(0, labels, ar, reduce="amin")
-    Cm = torch.zeros(n, r, dtype=torch.float32, device=labels.device)
-    Cm[ar, labels] = 1.0
+    # (comparison, not indexed assignment: nothing here may synchronise or stage a host scalar - it runs inside captures)
+    Cm = (labels.unsqueeze(1) == torch.arange(r, device=labels.device).unsqueeze(0)).to(torch.float32)
     return labels, rep, Cm, u, r, 1.0 / Cm.sum(0).clamp_min(1.0)
 
 

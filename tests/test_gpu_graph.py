@@ -61,10 +61,10 @@ def test_replay_takes_new_batches_by_copy_in(device):
     from matten_amd.graphs import GraphedStep
     from tests.parity import CONFIGS, Stack, _prep, make_batch
 
-    cfg = CONFIGS["minimal"]
+    cfg = CONFIGS["c3_lowrank"]  # >= 64 atoms: the self connection builds its class table (low-rank route)
     torch.manual_seed(35)
     raw = [make_batch(cfg, seed0=1000 + 100 * i) for i in range(3)]
-    for i, drop in ((1, 3), (2, 10)):  # (these small cells all have 624 edges: make the counts differ)
+    for i, drop in ((1, 3), (2, 10)):  # (equal cells give equal counts: make them differ)
         raw[i][K.EDGE_INDEX] = raw[i][K.EDGE_INDEX][:, :-drop].contiguous()
         raw[i][K.EDGE_CELL_SHIFT] = raw[i][K.EDGE_CELL_SHIFT][:-drop].contiguous()
     e_pad = max(int(b[K.EDGE_INDEX].shape[1]) for b in raw) + 7
