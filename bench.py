@@ -295,6 +295,11 @@ def main():
         raise SystemExit(subprocess.call(cmd))
     if world != args.gpus:
         raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}")
+    # stdout carries the ONE JSON line and nothing else: whatever native libraries print there (RCCL's version banner
+    # at the first collective) is sent to stderr, the line itself goes to the saved descriptor
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     dist = None
     if world > 1 or args.dist_single:
         import torch.distributed as dist
@@ -612,7 +617,8 @@ def main():
         out["radial_mlp_launches_per_step"] = rl
         if rl is not None and abs(rl - n_layers) > 1e-9:  # one radial network per layer and step, prefetched or not
             print(f"bench.py: WARNING {rl} radial-network launches per step for {n_layers} layers", file=sys.stderr)
-        print(json.dumps(out))
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
     if dist is not None:
         dist.destroy_process_group()
 

@@ -24,8 +24,15 @@ def _run(args, timeout=300):
 def test_bench_line_with_rccl_group_of_one(device):
     r = _run(["--gpus", "1", "--dist-single", "--steps", "3", "--warmup", "2", "--no-cpu-baseline"])
     assert r.returncode == 0, r.stderr[-2000:]
+    assert len(r.stdout.strip().splitlines()) == 1, r.stdout[:500]  # ONE line: RCCL's banner must not land on stdout
     line = json.loads(r.stdout.strip().splitlines()[-1])
     assert line["unit"] == "edge-layers/s" and line["n_gpus"] == 1 and line["steps"] == 3
+    # what a scaling run needs to explain itself, and the training-loop numbers beside the replay
+    assert line["per_rank"][0]["edges"] == line["config"]["edges_per_gpu"] and line["per_rank"][0]["allreduce_ms"] > 0
+    assert line["exposed_collective_ms"] > 0 and line["eager_ms_per_step"] > 0 and line["lib_sha256_16"]
+    fb = line["fresh_batch"]
+    assert fb and "error" not in fb and fb["ms_per_step"] > 0 and len(set(fb["edges"])) > 1 and fb["padded_edges"] >= max(fb["edges"])
+    assert line["mfma_roofline"]["self_connection"]["frac"] > 0
     assert abs(line["model_edges_per_s"] * line["config"]["conv_layers"] - line["value"]) < 1e-6 * line["value"]
     assert "all-reduce (nccl)" in line["config"]["step"]
     assert line["radial_mlp_launches_per_step"] == line["config"]["conv_layers"]  # no prefetch across the end of a pass
@@ -33,6 +40,14 @@ def test_bench_line_with_rccl_group_of_one(device):
     assert roof["bound"] == "hbm" and 0.05 < roof["frac"] < 1.0 and abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-9
     e, n = line["config"]["edges_per_gpu"], line["config"]["nodes_per_gpu"]
     assert abs(line["config"]["avg_num_neighbors"] - e / n) < 1e-9  # computed from the batch, not assumed
+
+
+def test_bench_allreduce_inside_the_graph(device):
+    """The RCCL all-reduce captured as a node of the HIP graph (group of one rank)."""
+    r = _run(["--gpus", "1", "--dist-single", "--graph-allreduce", "1", "--steps", "3", "--warmup", "2", "--no-cpu-baseline", "--fresh", "0"])
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line["allreduce_in_graph"] is True and line["config"]["launch"] == "hip_graph_replay"
 
 
 def test_bench_gpus_n_without_launcher(device):
