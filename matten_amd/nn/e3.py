@@ -41,6 +41,19 @@ def _n2m(name: str) -> float:
     return 1.0 if abs(c - 1.0) < 1e-4 else c
 
 
+def _act_name(act) -> str:
+    """Activation given by name, or as one of the callables the reference passes (eigenn/nn/utils.py:14-26: its
+    ShiftedSoftPlus, torch.nn.functional.silu, torch.sigmoid, torch.abs, torch.tanh)."""
+    if isinstance(act, str):
+        name = act
+    else:
+        name = getattr(act, "__name__", type(act).__name__).lower()
+        name = {"shiftedsoftplus": "ssp", "shifted_softplus": "ssp"}.get(name, name)
+    if name not in NORMALIZE2MOM or name not in ACT:
+        raise ValueError(f"matten_amd: unknown activation `{act}` (known: {sorted(set(NORMALIZE2MOM) & set(ACT))})")
+    return name
+
+
 def _row_blocks(irreps: Irreps):
     """(offset, mul, 2l+1) of every non-empty block of a feature row."""
     return tuple((off, m.mul, m.ir.dim) for off, m in zip(irreps.offsets(), irreps) if m.dim > 0)
@@ -95,9 +108,13 @@ class FullyConnectedTensorProduct(torch.nn.Module):
     instructions for every (i1, i2, io) with ir_out in ir1 x ir2 (loop order i1, i2, io),
     weight blocks [mul1, mul2, mul_out] flattened into one `weight`.
 
-    The kernels cover the case the layer uses - a scalar (l = 0) second input, i.e. the
-    species-embedding node attributes (eigenn/nn/point_conv.py:159-164).  Other second inputs
-    construct (as in the reference's tests/nn/test_convolution.py) but raise at call time."""
+    The fast route is the case the layer uses - a scalar (l = 0) second input, i.e. the species-embedding node
+    attributes (eigenn/nn/point_conv.py:159-164): one grouped MFMA product (ops.fctp).  Any other second input (the
+    reference's tests/nn/test_convolution.py gives the node attributes 4x1e+2x0e) takes the general route, built from
+    the same kernels in two steps: the Clebsch-Gordan contraction z[n, (v, u), k] = sum_ij C[i,j,k] x[n,u,i] a[n,v,j]
+    is the 'uvu' convolution kernel on an ordering in which every node is its own sender and receiver (one unit-weight
+    path per copy v of the second input), the channel mixing out[n,w,k] = sqrt(alpha) sum_{(v,u)} W[u,v,w] z[n,(v,u),k]
+    is an o3.Linear product.  Not tuned: it exists so that everything the reference can construct also runs."""
 
     def __init__(self, irreps_in1, irreps_in2, irreps_out):
         super().__init__()
@@ -114,20 +131,39 @@ class FullyConnectedTensorProduct(torch.nn.Module):
         ]
         ins, w_off = [], 0
         self._unsupported = None
+        self._general = any(self.irreps_in2[b].ir.l != 0 for _, b, _ in triples)
+        g_paths, g_lin, g_blocks, z_off, zw_off, lw_off = [], [], [], 0, 0, 0
         for a, b, c in triples:
             m1, m2, mo = self.irreps_in1[a], self.irreps_in2[b], self.irreps_out[c]
             fan = sum(self.irreps_in1[a2].mul * self.irreps_in2[b2].mul for a2, b2, c2 in triples if c2 == c)
             alpha = mo.ir.dim / fan if fan > 0 else 0.0
-            if m2.ir.l != 0:
-                self._unsupported = f"second input {self.irreps_in2} is not scalar"
-            elif m1.mul * m2.mul * mo.mul > 0:
-                # C(l,0,l)[i,0,k] = delta_ik / sqrt(2l+1)
-                coeff = math.sqrt(alpha) / math.sqrt(mo.ir.dim)
-                ins.append((o1[a], m1.mul, o2[b], m2.mul, oo[c], mo.mul, mo.ir.dim, w_off, coeff))
+            if m1.mul * m2.mul * mo.mul > 0:
+                if self._general:
+                    if max(m1.ir.l, m2.ir.l, mo.ir.l) > 3:
+                        self._unsupported = "l > 3"
+                    g_lin.append((z_off, m2.mul * m1.mul, oo[c], mo.mul, mo.ir.dim, lw_off, math.sqrt(alpha)))
+                    g_blocks.append((w_off, m1.mul, m2.mul, mo.mul))
+                    for v in range(m2.mul):
+                        g_paths.append(dict(l1=m1.ir.l, l2=m2.ir.l, l3=mo.ir.l, mul=m1.mul, x_off=o1[a], y_off=o2[b] + v * m2.ir.dim,
+                                            out_off=z_off, w_off=zw_off, coeff=1.0))
+                        z_off += m1.mul * mo.ir.dim
+                        zw_off += m1.mul
+                    lw_off += m1.mul * m2.mul * mo.mul
+                else:
+                    # C(l,0,l)[i,0,k] = delta_ik / sqrt(2l+1)
+                    coeff = math.sqrt(alpha) / math.sqrt(mo.ir.dim)
+                    ins.append((o1[a], m1.mul, o2[b], m2.mul, oo[c], mo.mul, mo.ir.dim, w_off, coeff))
             w_off += m1.mul * m2.mul * mo.mul
         self.weight_numel = w_off
         self.weight = torch.nn.Parameter(torch.randn(w_off))
         cov = lambda irreps, idx: all(i in idx or irreps[i].dim == 0 for i in range(len(irreps)))
+        if self._general and self._unsupported is None:
+            self._g_blocks, self._g_w = tuple(g_blocks), zw_off
+            self._g_plan = ops.ConvPlan(g_paths, self.irreps_in1.dim, self.irreps_in2.dim, z_off, zw_off)
+            self._g_lin = ops.LinearSpec(
+                d_in=z_off, d_out=self.irreps_out.dim, weight_numel=lw_off, instructions=tuple(g_lin),
+                out_covered=cov(self.irreps_out, {c for _, _, c in triples}), in_covered=True, out_blocks=_row_blocks(self.irreps_out),
+            )
         self.spec = ops.FctpSpec(
             d_x=self.irreps_in1.dim,
             d_a=self.irreps_in2.dim,
@@ -143,6 +179,15 @@ class FullyConnectedTensorProduct(torch.nn.Module):
     def forward(self, x, a, base: Optional[torch.Tensor] = None, classes: Optional[torch.Tensor] = None):
         if self._unsupported:
             raise NotImplementedError(f"matten_amd FullyConnectedTensorProduct: {self._unsupported}")
+        if self._general:
+            n = x.shape[0]
+            ordering = ops.self_ordering(n, x.device)
+            ones = torch.ones(n, self._g_w, dtype=torch.float32, device=x.device)
+            z = ops.conv(x, a, ones, self._g_plan, ordering, 1.0, False)
+            # e3nn keeps a block as [u, v, w]; the Linear contracts over (v, u), the layout the convolution wrote
+            wl = torch.cat([self.weight[o : o + m1 * m2 * mo].view(m1, m2, mo).permute(1, 0, 2).reshape(-1) for o, m1, m2, mo in self._g_blocks])
+            out = ops.linear(z, wl, self._g_lin)
+            return out if base is None else out + base
         return ops.fctp(x, a, self.weight, self.spec, base, classes=classes)
 
     def extra_repr(self):
@@ -162,8 +207,7 @@ class FullyConnectedNet(torch.nn.Module):
     def __init__(self, hs: Sequence[int], act: str = "ssp"):
         super().__init__()
         self.hs = [int(h) for h in hs]
-        if act != "ssp":
-            raise NotImplementedError("matten_amd FullyConnectedNet: only the shifted-softplus activation is built")
+        act = _act_name(act)
         self.act = act
         self.act_cst = _n2m(act)
         for i, (a, b) in enumerate(zip(self.hs, self.hs[1:])):
@@ -174,9 +218,15 @@ class FullyConnectedNet(torch.nn.Module):
 
     def forward(self, x, pre=None):
         """`pre`: this network's activations for `x`, from precompute() (see ops.radial_mlp)."""
+        if self.act != "ssp":
+            # the fused kernels are written for the shifted softplus (the only activation the two target models use,
+            # eigenn/nn/utils.py:182); the others run layer by layer on the dense product and the gate kernel
+            return ops.radial_mlp_general(x, self._weights(), self.act_cst, ACT[self.act])
         return ops.radial_mlp(x, self._weights(), self.act_cst, pre)
 
     def precompute(self, x):
+        if self.act != "ssp":
+            return None
         return ops.radial_mlp_precompute(x, self._weights(), self.act_cst)
 
     def extra_repr(self):
@@ -281,26 +331,58 @@ class UVUTensorProductCore(torch.nn.Module):
             if m1.mul != mo.mul:
                 raise ValueError("'uvu' needs mul_in1 == mul_out")
             fan = sum(self.irreps_in2[j2].mul for _, j2, jo in self.instructions if jo == io)
-            if m2.mul != 1:
-                self._unsupported = f"edge attributes {self.irreps_in2} have a block of multiplicity {m2.mul} != 1"
             if max(m1.ir.l, m2.ir.l, mo.ir.l) > 3:
                 self._unsupported = "l > 3"
             paths.append(
                 dict(l1=m1.ir.l, l2=m2.ir.l, l3=mo.ir.l, mul=m1.mul, x_off=o1[i1], y_off=o2[i2], out_off=oo[io],
-                     w_off=w_off, coeff=math.sqrt(mo.ir.dim / fan))
+                     w_off=w_off, coeff=math.sqrt(mo.ir.dim / fan), mul2=m2.mul, io=io)
             )
             w_off += m1.mul * m2.mul
         self.weight_numel = w_off
-        self.plan = (
-            ops.ConvPlan([p for p in paths if p["mul"] > 0], self.irreps_in1.dim, self.irreps_in2.dim, self.irreps_out.dim, w_off,
-                         out_blocks=_row_blocks(self.irreps_out.simplify()))  # the blocks of the o3.Linear that follows
-            if self._unsupported is None
-            else None
-        )
+        # Second inputs with blocks of multiplicity > 1 (not spherical harmonics: the reference's own constructor test
+        # gives the edge attributes 4x1e+2x0e): the weight block of a path is [mul_1, mul_2] and the path sums over the
+        # copies v.  The kernel's paths have one copy, so the instruction is laid out as mul_2 paths - copy v of the block
+        # is itself a block of multiplicity 1 at y_off + v (2 l2 + 1) - each with a slot of its own in a wider output
+        # row, the per-edge weights are re-ordered to [path, v][u] and the slots of a path are added up afterwards.
+        self._expanded = self._unsupported is None and any(p["mul2"] != 1 for p in paths)
+        if self._unsupported is not None:
+            self.plan = None
+        elif not self._expanded:
+            self.plan = ops.ConvPlan([{k: v for k, v in p.items() if k not in ("mul2", "io")} for p in paths if p["mul"] > 0],
+                                     self.irreps_in1.dim, self.irreps_in2.dim, self.irreps_out.dim, w_off,
+                                     out_blocks=_row_blocks(self.irreps_out.simplify()))  # the blocks of the o3.Linear that follows
+        else:
+            ex, perm, slots, e_off, ew_off = [], [], [], 0, 0
+            for p in paths:
+                if p["mul"] == 0:
+                    continue
+                blk = p["mul"] * (2 * p["l3"] + 1)
+                slots.append((p["io"], e_off, p["mul2"], blk))
+                for v in range(p["mul2"]):
+                    ex.append(dict(l1=p["l1"], l2=p["l2"], l3=p["l3"], mul=p["mul"], x_off=p["x_off"], y_off=p["y_off"] + v * (2 * p["l2"] + 1),
+                                   out_off=e_off, w_off=ew_off, coeff=p["coeff"]))
+                    perm += [p["w_off"] + u * p["mul2"] + v for u in range(p["mul"])]
+                    e_off += blk
+                    ew_off += p["mul"]
+            self.plan = ops.ConvPlan(ex, self.irreps_in1.dim, self.irreps_in2.dim, e_off, ew_off)
+            self.register_buffer("_w_perm", torch.tensor(perm, dtype=torch.int64), persistent=False)
+            self._slots = tuple(slots)
 
     def forward(self, x, y, weight, ordering: ops.EdgeOrdering, scale: float = 1.0, per_edge: bool = False):
         if self._unsupported:
             raise NotImplementedError(f"matten_amd uvu tensor product: {self._unsupported}")
+        if self._expanded:
+            wide = ops.conv(x, y, weight.index_select(1, self._w_perm), self.plan, ordering, scale, per_edge)
+            n = wide.shape[0]
+            parts = []
+            for io, m in enumerate(self.irreps_out):
+                acc = None
+                for jo, e_off, mul2, blk in self._slots:
+                    if jo == io:
+                        t = wide[:, e_off : e_off + mul2 * blk].reshape(n, mul2, blk).sum(1)
+                        acc = t if acc is None else acc + t
+                parts.append(acc if acc is not None else wide.new_zeros(n, m.dim))
+            return torch.cat(parts, dim=1)
         return ops.conv(x, y, weight, self.plan, ordering, scale, per_edge)
 
     def extra_repr(self):

@@ -141,7 +141,7 @@ class UVUTensorProduct(torch.nn.Module):
             assert mlp_input_size is not None, (
                 "Expect `mlp_input_size` be provided when `internal_and_share_weights` is set to `False`, got `None`"
             )
-            act = mlp_activation if isinstance(mlp_activation, str) else "ssp"
+            act = mlp_activation  # a name, or one of the reference's callables (nn/e3.py:_act_name)
             layer_sizes = [mlp_input_size] + mlp_num_hidden_layers * [mlp_hidden_size] + [self.tp.weight_numel]
             self.weight_nn = FullyConnectedNet(layer_sizes, act=act)
 

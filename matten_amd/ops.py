@@ -199,6 +199,7 @@ def clear_caches():
     torch.cuda.synchronize()
     check_edge_orderings(wait=True)
     _ORDER_CACHE.clear()
+    _SELF_ORDERINGS.clear()
     _TRANSPOSED.clear()
     _ATTR_FACTORS.clear()
     _ATTR_CLASSES.clear()
@@ -1209,15 +1210,41 @@ class _MatmulFn(torch.autograd.Function):
         return da, db, None, None, None
 
 
-def _radial_mlp_composite(x, ws, act_cst: float):
-    """The radial network out of ops that are differentiable to any order (used for double backward)."""
+def _radial_mlp_composite(x, ws, act_cst: float, act_id: Optional[int] = None):
+    """The radial network out of ops that are differentiable to any order (used for double backward, and as the
+    forward of networks whose activation is not the shifted softplus)."""
+    act_id = _lib.ACT["ssp"] if act_id is None else int(act_id)
     h = x
     for i, w in enumerate(ws):
         h = _MatmulFn.apply(h, w, False, False, 1.0 / math.sqrt(w.shape[0]))
         if i < len(ws) - 1:
             d = w.shape[1]
-            h = _GateFn.apply(h, GateSpec(d_in=d, d_out=d, segs=((0, 0, d, 1, -1, _lib.ACT["ssp"], float(act_cst)),)))
+            h = _GateFn.apply(h, GateSpec(d_in=d, d_out=d, segs=((0, 0, d, 1, -1, act_id, float(act_cst)),)))
     return h
+
+
+def radial_mlp_general(x, weights: Sequence[torch.Tensor], act_cst: float, act_id: int):
+    """FullyConnectedNet with any of the gate kernel's activations (eigenn/nn/utils.py:182 `mlp_activation`), layer by
+    layer: dense product, then the activation as a one-segment gate."""
+    return _radial_mlp_composite(x, list(weights), act_cst, act_id)
+
+
+_SELF_ORDERINGS: "dict[tuple, tuple]" = {}
+
+
+def self_ordering(n: int, device) -> "EdgeOrdering":
+    """Ordering of the graph in which node i has the one edge i -> i (general FullyConnectedTensorProduct, nn/e3.py)."""
+    device = torch.device(device)
+    key = (device.index if device.index is not None else torch.cuda.current_device(), int(n))
+    hit = _SELF_ORDERINGS.get(key)
+    if hit is None:
+        ar = torch.arange(n, dtype=torch.int64, device=device)
+        ei = torch.stack([ar, ar])
+        hit = (ei, EdgeOrdering(ei, n))
+        if len(_SELF_ORDERINGS) >= 8:
+            _SELF_ORDERINGS.pop(next(iter(_SELF_ORDERINGS)))
+        _SELF_ORDERINGS[key] = hit
+    return hit[1]
 
 
 def radial_mlp(x, weights: Sequence[torch.Tensor], act_cst: float, pre=None):

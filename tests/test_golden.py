@@ -98,18 +98,59 @@ def test_hip_reproduces_pointconv_golden(device):
     _compare_pointconv(G.run(layer, *args), 1e-5)
 
 
+# ------------------------------------------------------------------ the reference test's literal irreps (pointconv_literal.npz)
+def _pointconv_literal(impl):
+    from tests.golden import make_pointconv_literal_golden as G
+
+    if impl == "oracle":
+        from oracle import eigenn_ref as M
+    else:
+        import matten_amd.nn as M
+    torch.manual_seed(35)
+    return M.PointConv(G.IRREPS_IN, G.IRREPS_OUT, **G.KWARGS), G
+
+
+def _compare_literal(res, tol):
+    z = np.load(os.path.join(HERE, "golden", "pointconv_literal.npz"), allow_pickle=False)
+    keys = [k for k in z.files if k != "weight_guard"]
+    assert sorted(keys) == sorted(res)
+    for k in keys:
+        assert rel_err(res[k], torch.from_numpy(z[k])) <= tol, k
+    return z
+
+
+def test_oracle_reproduces_pointconv_literal_golden():
+    layer, G = _pointconv_literal("oracle")
+    res = G.run(layer.double(), *G.inputs())
+    z = _compare_literal(res, 1e-12)
+    assert np.allclose(layer.linear_1.weight.detach()[:8].numpy(), z["weight_guard"])
+
+
 @pytest.mark.gpu
-def test_hip_pointconv_refuses_what_the_kernels_do_not_cover(device):
-    """The reference's literal test irreps (edge attributes of multiplicity 4, non-scalar node
-    attributes) construct, as its test requires, and raise NotImplementedError when called."""
+def test_hip_reproduces_pointconv_literal_golden(device):
+    """What the reference's own test constructs (tests/nn/test_convolution.py:8-21: edge attributes 4x1e+2x0e, i.e.
+    second-input blocks of multiplicity 4 and 2 in the 'uvu' product, and NON-scalar node attributes in the self
+    connection) runs forward and backward on the HIP kernels and matches the oracle's fixture."""
+    ref, G = _pointconv_literal("oracle")
+    layer, _ = _pointconv_literal("hip")
+    assert layer.tp.tp._expanded and layer.self_connection._general
+    layer.load_state_dict(ref.state_dict(), strict=True)
+    layer = layer.to(device)
+    args = [t.to(device) if not t.is_floating_point() else t.float().to(device) for t in G.inputs()]
+    _compare_literal(G.run(layer, *args), 1e-5)
+
+
+@pytest.mark.gpu
+def test_hip_refuses_l_above_3(device):
+    """What the kernels do not cover (l > 3) constructs and raises NotImplementedError when called."""
     import matten_amd.nn as H
 
     conv = H.PointConv(
-        irreps_in={"node_features": "4x1e+2x0e", "node_attrs": "4x1e+2x0e", "edge_attrs": "4x1e+2x0e", "edge_embedding": "4x0e"},
-        irreps_out={"node_features": "8x1e+4x0e"},
+        irreps_in={"node_features": "2x4e+2x0e", "node_attrs": "3x0e", "edge_attrs": "0e+1o", "edge_embedding": "4x0e"},
+        irreps_out={"node_features": "2x4e+4x0e"},
     ).to(device)
-    data = {"node_features": torch.randn(5, 14, device=device), "node_attrs": torch.randn(5, 14, device=device),
-            "edge_attrs": torch.randn(9, 14, device=device), "edge_embedding": torch.randn(9, 4, device=device),
+    data = {"node_features": torch.randn(5, 20, device=device), "node_attrs": torch.randn(5, 3, device=device),
+            "edge_attrs": torch.randn(9, 4, device=device), "edge_embedding": torch.randn(9, 4, device=device),
             "edge_index": torch.randint(0, 5, (2, 9), device=device)}
     with pytest.raises(NotImplementedError):
         conv(data)

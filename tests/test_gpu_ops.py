@@ -261,6 +261,103 @@ def test_radial_mlp_vs_oracle(device, hs):
         assert rel(g_, r) < TOL
 
 
+@pytest.mark.parametrize("act", ["silu", "sigmoid"])
+def test_radial_mlp_other_activations_vs_oracle(device, act):
+    """mlp_activation other than the shifted softplus (eigenn/nn/utils.py:182,252), forward, backward and through
+    UVUTensorProduct's constructor argument (by name and as the callable the reference passes)."""
+    from matten_amd.nn.e3 import FullyConnectedNet
+    from matten_amd.nn.utils import UVUTensorProduct
+    from oracle import e3ref
+
+    fn = {"silu": torch.nn.functional.silu, "sigmoid": torch.sigmoid}[act]
+    hs = [8, 64, 64, 96]
+    torch.manual_seed(4)
+    o = e3ref.FullyConnectedNet(hs, act=fn, act_key=act).double()
+    h = FullyConnectedNet(hs, act=act)
+    _pair_state(o, h)
+    h = h.to(device)
+    x = torch.randn(777, hs[0], dtype=torch.float64, requires_grad=True)
+    xg = x.detach().float().to(device).requires_grad_(True)
+    y, yg = o(x), h(xg)
+    assert rel(yg, y) < TOL
+    go = torch.randn_like(y)
+    ref = torch.autograd.grad(y, [x] + list(o.parameters()), go)
+    got = torch.autograd.grad(yg, [xg] + list(h.parameters()), go.float().to(device))
+    for r, g_ in zip(ref, got):
+        assert rel(g_, r) < TOL
+    for arg in (act, fn):
+        tp = UVUTensorProduct("8x0e+4x1o", "0e+1o+2e", "8x0e+4x1o", mlp_input_size=4, mlp_activation=arg)
+        assert tp.weight_nn.act == act
+    with pytest.raises(ValueError):
+        UVUTensorProduct("8x0e+4x1o", "0e+1o+2e", "8x0e+4x1o", mlp_input_size=4, mlp_activation="relu6")
+
+
+@pytest.mark.parametrize(
+    "in1,in2,out",
+    [
+        ("4x1e+2x0e", "4x1e+2x0e", "8x1e+4x0e"),
+        ("3x0e+2x1o+2x2e", "2x1o+1x2e+2x0e", "4x0e+3x1o+2x1e+2x2e+2x3o"),
+    ],
+)
+def test_fctp_general_second_input_vs_oracle(device, in1, in2, out):
+    """FullyConnectedTensorProduct with a NON-scalar second input (the reference's constructor test gives the node
+    attributes 4x1e+2x0e): forward, input and weight gradients, and the accumulation onto a base."""
+    from matten_amd.nn.e3 import FullyConnectedTensorProduct
+    from oracle import e3ref
+
+    torch.manual_seed(6)
+    o = e3ref.FullyConnectedTensorProduct(in1, in2, out).double()
+    h = FullyConnectedTensorProduct(in1, in2, out)
+    assert h._general and h.weight_numel == o.weight.numel()
+    h.load_state_dict({"weight": o.weight.detach().float()}, strict=False)
+    h = h.to(device)
+    n = 57
+    x = torch.randn(n, o.irreps_in1.dim, dtype=torch.float64, requires_grad=True)
+    a = torch.randn(n, o.irreps_in2.dim, dtype=torch.float64, requires_grad=True)
+    base = torch.randn(n, o.irreps_out.dim, dtype=torch.float64)
+    xg, ag = (t.detach().float().to(device).requires_grad_(True) for t in (x, a))
+    y = o(x, a) + base
+    yg = h(xg, ag, base=base.float().to(device))
+    assert rel(yg, y) < TOL
+    go = torch.randn_like(y)
+    ref = torch.autograd.grad(y, [x, a, o.weight], go)
+    got = torch.autograd.grad(yg, [xg, ag, h.weight], go.float().to(device))
+    for r, g_ in zip(ref, got):
+        assert rel(g_, r) < TOL
+
+
+def test_uvu_second_input_multiplicity_vs_oracle(device):
+    """'uvu' tensor product whose second input has blocks of multiplicity > 1 (weight blocks [mul_1, mul_2]),
+    fused with gather and per-receiver sum, against the oracle's unfused op order."""
+    from matten_amd.nn.utils import UVUTensorProduct
+    from oracle import eigenn_ref as R
+
+    torch.manual_seed(8)
+    args = ("4x1e+2x0e+3x1o", "4x1e+2x0e+2x2e", "8x1e+4x0e+3x1o+2x2o")
+    o = R.UVUTensorProduct(*args, mlp_input_size=4, mlp_hidden_size=8, mlp_num_hidden_layers=1).double()
+    h = UVUTensorProduct(*args, mlp_input_size=4, mlp_hidden_size=8, mlp_num_hidden_layers=1)
+    assert h.tp._expanded and str(h.irreps_out) == str(o.irreps_out)
+    _pair_state(o, h)
+    h = h.to(device)
+    n, e = 19, 140
+    ei = random_graph(n, e, 61, device)
+    x = torch.randn(n, h.tp.irreps_in1.dim, dtype=torch.float64, requires_grad=True)
+    y = torch.randn(e, h.tp.irreps_in2.dim, dtype=torch.float64, requires_grad=True)
+    emb = torch.randn(e, 4, dtype=torch.float64, requires_grad=True)
+    xg, yg, eg = (t.detach().float().to(device).requires_grad_(True) for t in (x, y, emb))
+    from matten_amd import ops
+
+    msg = o(x[ei[0].cpu()], y, emb)
+    ref_out = torch.zeros(n, msg.shape[1], dtype=torch.float64).index_add_(0, ei[1].cpu(), msg)
+    got_out = h(xg, yg, eg, ordering=ops.edge_ordering(ei, n))
+    assert rel(got_out, ref_out) < TOL
+    go = torch.randn_like(ref_out)
+    ref = torch.autograd.grad(ref_out, [x, y, emb] + list(o.parameters()), go)
+    got = torch.autograd.grad(got_out, [xg, yg, eg] + list(h.parameters()), go.float().to(device))
+    for r, g_ in zip(ref, got):
+        assert rel(g_, r) < TOL
+
+
 @pytest.mark.parametrize(
     "scalars,acts_s,gates,acts_g,gated",
     [
