@@ -529,6 +529,11 @@ int tfc_norm_act_fwd(const tfc_gate_seg* segs, int32_t n_segs, const float* x, i
 int tfc_norm_act_bwd(const tfc_gate_seg* segs, int32_t n_segs, const float* x, const float* gout,
                      int64_t n_rows, int32_t d, float eps_squared, int32_t normalize, float* dx,
                      tfc_stream_t stream);
+/* Second order (what autograd derives when the reference trains on a gradient, eigenn/nn/utils.py:142-150): `v` is a
+ * cotangent of dx; gx receives the cotangent of x, d/dx (v^T J(x) gout).  The Jacobian is symmetric, so the cotangent
+ * of gout is tfc_norm_act_bwd with v in the place of gout. */
+int tfc_norm_act_bwd2(const tfc_gate_seg* segs, int32_t n_segs, const float* x, const float* gout, const float* v,
+                      int64_t n_rows, int32_t d, float eps_squared, int32_t normalize, float* gx, tfc_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * Opt-in kernel timing (no counterpart in the reference, whose only timer is the epoch wall

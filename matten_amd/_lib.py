@@ -163,6 +163,7 @@ SIGNATURES = {
     "tfc_gate_fwd": (C.c_int, [C.POINTER(GateSeg), _I32, _P, _I64, _I32, _I32, _P, _P]),
     "tfc_norm_act_fwd": (C.c_int, [C.POINTER(GateSeg), _I32, _P, _I64, _I32, _F, _I32, _P, _P]),
     "tfc_norm_act_bwd": (C.c_int, [C.POINTER(GateSeg), _I32, _P, _P, _I64, _I32, _F, _I32, _P, _P]),
+    "tfc_norm_act_bwd2": (C.c_int, [C.POINTER(GateSeg), _I32, _P, _P, _P, _I64, _I32, _F, _I32, _P, _P]),
     "tfc_profile_enable": (C.c_int, [C.c_int]),
     "tfc_profile_reset": (C.c_int, []),
     "tfc_profile_report": (C.c_int, [C.c_char_p, _I64]),

@@ -382,6 +382,45 @@ __global__ __launch_bounds__(256) void tfc_norm_act_kernel(const GateSegs g, con
     }
 }
 
+// Second order of the norm activation.  Per copy out = s(n) x with n = |x| and s = act(n) [/ n], so the Jacobian
+// J = s I + q x x^T (q = s'(n) / n) is symmetric: the cotangent of gout under a cotangent v of dx is J v, i.e. the
+// first-order backward applied to v (no kernel of its own), and the cotangent of x is
+//   d/dx ( v^T J g ) = ( q (v.g) + q'(n)/n (x.v)(x.g) ) x + q ( (x.g) v + (x.v) g ),
+// zero for a clamped copy (its scale is the constant act(eps) [/ eps]).
+__global__ __launch_bounds__(256) void tfc_norm_act_bwd2_kernel(const GateSegs g, const float* __restrict__ x,
+                                                                const float* __restrict__ gout, const float* __restrict__ v,
+                                                                long n_rows, int d, float eps2, int normalize,
+                                                                float* __restrict__ gx) {
+    const long total = n_rows * (long)d;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long r = i / d;
+        const int c = (int)(i - r * d);
+        tfc_gate_seg sg;
+        int base;
+        float o = 0.f;
+        if (norm_find(g, c, sg, base)) {
+            const long b = r * (long)d + base;
+            float n2 = 0.f, xg = 0.f, xv = 0.f, vg = 0.f;
+            for (int m = 0; m < sg.dim; ++m) {
+                const float xm = x[b + m], gm = gout[b + m], vm = v[b + m];
+                n2 = fmaf(xm, xm, n2);
+                xg = fmaf(xm, gm, xg);
+                xv = fmaf(xm, vm, xv);
+                vg = fmaf(vm, gm, vg);
+            }
+            if (!(eps2 > 0.f && n2 < eps2)) {
+                const float n = sqrtf(n2);
+                const float a = act_eval(sg.act, n), a1 = act_grad(sg.act, n), a2 = act_grad2(sg.act, n);
+                const float s1 = normalize ? (a1 * n - a) / (n * n) : a1;
+                const float s2 = normalize ? (a2 * n * n - 2.f * a1 * n + 2.f * a) / (n * n * n) : a2;
+                const float q = s1 / n, qp = (s2 * n - s1) / (n * n);
+                o = (q * vg + qp / n * xv * xg) * x[i] + q * (xg * v[i] + xv * gout[i]);
+            }
+        }
+        gx[i] = o;
+    }
+}
+
 int pack_norm_segs(const tfc_gate_seg* segs, int32_t n_segs, int32_t d, GateSegs* out) {
     TFC_REQUIRE(segs && n_segs > 0 && n_segs <= MAX_SEGS, TFC_EINVAL, "tfc_norm_act: n_segs=%d outside 1..%d", n_segs,
                 MAX_SEGS);
@@ -569,5 +608,22 @@ extern "C" int tfc_norm_act_bwd(const tfc_gate_seg* segs, int32_t n_segs, const 
     TfcProfScope prof("tfc_norm_act_bwd_kernel", stream);
     tfc_norm_act_kernel<true><<<grid, 256, 0, stream>>>(g, x, gout, (long)n_rows, d, eps_squared, normalize, dx);
     TFC_LAUNCH_CHECK("tfc_norm_act_kernel<bwd>");
+    return TFC_OK;
+}
+
+extern "C" int tfc_norm_act_bwd2(const tfc_gate_seg* segs, int32_t n_segs, const float* x, const float* gout, const float* v,
+                                 int64_t n_rows, int32_t d, float eps_squared, int32_t normalize, float* gx,
+                                 tfc_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    TFC_REQUIRE(n_rows >= 0 && d > 0 && eps_squared >= 0.f, TFC_EINVAL, "tfc_norm_act_bwd2: bad size");
+    GateSegs g;
+    int rc = pack_norm_segs(segs, n_segs, d, &g);
+    if (rc != TFC_OK) return rc;
+    if (n_rows == 0) return TFC_OK;
+    TFC_REQUIRE(x && gout && v && gx, TFC_EINVAL, "tfc_norm_act_bwd2: null tensor");
+    const int grid = (int)std::min<long>((n_rows * (long)d + 255) / 256, 8192);
+    TfcProfScope prof("tfc_norm_act_bwd2_kernel", stream);
+    tfc_norm_act_bwd2_kernel<<<grid, 256, 0, stream>>>(g, x, gout, v, (long)n_rows, d, eps_squared, normalize, gx);
+    TFC_LAUNCH_CHECK("tfc_norm_act_bwd2_kernel");
     return TFC_OK;
 }

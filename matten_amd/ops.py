@@ -674,6 +674,7 @@ class _EdgeGeometryFn(torch.autograd.Function):
         ctx.save_for_backward(vec, length)
         ctx.cell_args = (shift, batch, G, cell.shape) if shift is not None else None
         ctx.ordering, ctx.lmax, ctx.sh_normalize = ordering, lmax, bool(sh_normalize)
+        ctx.n_nodes = N
         ctx.set_materialize_grads(False)
         if sh is None:
             return vec, length
@@ -686,11 +687,32 @@ class _EdgeGeometryFn(torch.autograd.Function):
         dvec, _ = _edge_bwd(vec, length, ctx.lmax, ctx.sh_normalize, None, 1.0, 6.0, dsh, None, dvec_in, dlen, False)
         dcell = None
         if ctx.needs_input_grad[2] and ctx.cell_args is not None:
-            if torch.is_grad_enabled():
-                raise NotImplementedError("matten_amd: double backward through the gradient of `cell` is not built")
             shift, batch, G, _ = ctx.cell_args
-            dcell = _dvec_to_dcell(dvec, shift, batch, G, ctx.ordering) if E else torch.zeros(G, 3, 3, dtype=torch.float32, device=vec.device)
+            if not E:
+                dcell = torch.zeros(G, 3, 3, dtype=torch.float32, device=vec.device)
+            elif torch.is_grad_enabled():
+                dcell = _DvecToDcellFn.apply(dvec, shift, batch, G, ctx.ordering, ctx.n_nodes)
+            else:
+                dcell = _dvec_to_dcell(dvec, shift, batch, G, ctx.ordering)
         return _dvec_to_dpos(dvec, ctx.ordering), None, dcell, None, None, None, None
+
+
+class _DvecToDcellFn(torch.autograd.Function):
+    """dcell[g] = sum over the edges of graph g of shift[e]^T (x) dvec[e], as a differentiable op.  It is linear in dvec
+    and its transpose, dvec[e] = shift[e] . dcell[graph of e], is what the edge-vector kernel computes from zero
+    positions - itself a differentiable op, so this goes to any order."""
+
+    @staticmethod
+    def forward(ctx, dvec, shift, batch, G: int, ordering: EdgeOrdering, n_nodes: int):
+        ctx.args = (shift, batch, G, ordering, n_nodes)
+        return _dvec_to_dcell(_f32(dvec, "dvec"), shift, batch, G, ordering)
+
+    @staticmethod
+    def backward(ctx, g):
+        shift, batch, G, ordering, n_nodes = ctx.args
+        zero = torch.zeros(n_nodes, 3, dtype=torch.float32, device=g.device)
+        out = _EdgeGeometryFn.apply(zero, shift, g.reshape(-1, 3, 3), batch, ordering, -1, True)
+        return out[0], None, None, None, None, None
 
 
 def edge_geometry(pos, ordering: EdgeOrdering, shift=None, cell=None, batch=None, lmax: int = -1, sh_normalize: bool = True):
@@ -1711,15 +1733,47 @@ class _NormActFn(torch.autograd.Function):
         return out
 
     @staticmethod
-    @torch.autograd.function.once_differentiable  # (the second order of the norm activation is not built: raises)
     def backward(ctx, g):
         (x,) = ctx.saved_tensors
         spec, eps_squared, normalize = ctx.args
-        g = _f32(g, "grad_output")
-        dx = torch.empty_like(x)
-        _lib.check(_lib.lib().tfc_norm_act_bwd(spec.c_array(), len(spec.segs), _ptr(x), _ptr(g), x.shape[0], spec.d_in, eps_squared,
-                                               1 if normalize else 0, _ptr(dx), _stream()))
-        return dx, None, None, None
+        if torch.is_grad_enabled():  # create_graph=True: the backward as a differentiable op
+            return _NormActBwdFn.apply(x, g, spec, eps_squared, normalize), None, None, None
+        return _norm_act_bwd_raw(x, _f32(g, "grad_output"), spec, eps_squared, normalize), None, None, None
+
+
+def _norm_act_bwd_raw(x, g, spec: "GateSpec", eps_squared: float, normalize: bool):
+    dx = torch.empty_like(x)
+    _lib.check(_lib.lib().tfc_norm_act_bwd(spec.c_array(), len(spec.segs), _ptr(x), _ptr(g), x.shape[0], spec.d_in, eps_squared,
+                                           1 if normalize else 0, _ptr(dx), _stream()))
+    return dx
+
+
+class _NormActBwdFn(torch.autograd.Function):
+    """dx = J(x)^T g of the norm activation as a differentiable op (second order; third order is not built).  J is
+    symmetric, so the cotangent of g is the same kernel applied to the incoming cotangent; the cotangent of x is
+    tfc_norm_act_bwd2."""
+
+    @staticmethod
+    def forward(ctx, x, g, spec: GateSpec, eps_squared: float, normalize: bool):
+        x, g = _f32(x, "x"), _f32(g, "grad_output")
+        ctx.save_for_backward(x, g)
+        ctx.args = (spec, eps_squared, normalize)
+        return _norm_act_bwd_raw(x, g, spec, eps_squared, normalize)
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, v):
+        x, g = ctx.saved_tensors
+        spec, eps_squared, normalize = ctx.args
+        v = _f32(v, "v")
+        gx = gg = None
+        if ctx.needs_input_grad[0]:
+            gx = torch.empty_like(x)
+            _lib.check(_lib.lib().tfc_norm_act_bwd2(spec.c_array(), len(spec.segs), _ptr(x), _ptr(g), _ptr(v), x.shape[0], spec.d_in,
+                                                    eps_squared, 1 if normalize else 0, _ptr(gx), _stream()))
+        if ctx.needs_input_grad[1]:
+            gg = _norm_act_bwd_raw(x, v, spec, eps_squared, normalize)
+        return gx, gg, None, None, None
 
 
 def norm_activation(x, spec: GateSpec, eps_squared: float = 0.0, normalize: bool = True):

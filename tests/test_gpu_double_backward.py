@@ -284,7 +284,7 @@ def test_force_training_step_through_the_energy_model(device):
     assert losses[-1] < losses[0]
 
 
-def test_third_order_and_norm_activation_raise(device):
+def test_third_order_raises(device):
     """What is not built says so instead of returning a silently constant gradient."""
     from matten_amd.nn.e3 import Gate
 
@@ -294,11 +294,64 @@ def test_third_order_and_norm_activation_raise(device):
     (g2,) = torch.autograd.grad(g1.square().sum(), [x], create_graph=True)
     with pytest.raises(RuntimeError):  # (torch: "once_differentiable" or "not used in the graph", by version)
         torch.autograd.grad(g2.square().sum(), [x])
-    import matten_amd.nn as H
-    from matten_amd.nn.utils import ActivationLayer
 
-    act = ActivationLayer("8x0e+4x1o", "0e+1o", "8x0e+4x1o", activation_type="norm")
-    x = torch.randn(5, act.irreps_in.dim, device=device, requires_grad=True)
-    (g1,) = torch.autograd.grad(act(x).sum(), [x], create_graph=True)
-    with pytest.raises(RuntimeError):
-        torch.autograd.grad(g1.square().sum(), [x])
+
+@pytest.mark.parametrize("normalize,act", [(True, "ssp"), (True, "tanh"), (False, "silu")])
+def test_norm_activation_second_order_vs_oracle(device, normalize, act):
+    """activation_type="norm" (eigenn/nn/utils.py:142-150) under create_graph=True: the gradient of a function of the
+    first gradient, with respect to the input and to the upstream gradient (tfc_norm_act_bwd2), one clamped copy included."""
+    from matten_amd.nn.e3 import NormActivation
+    from oracle import e3ref
+    from oracle.eigenn_ref import ACTIVATION
+
+    fn = {**ACTIVATION["e"], **ACTIVATION["o"]}[act]
+    irreps = "6x0e+5x1o+4x2e+3x3o"
+    o = e3ref.NormActivation(irreps, fn, normalize=normalize)
+    h = NormActivation(irreps, act, normalize=normalize)
+    torch.manual_seed(12)
+    x = torch.randn(41, o.irreps_in.dim, dtype=torch.float64)
+    if act == "tanh":
+        # a copy below epsilon: constant scale act(eps) / eps, no gradient through its norm (tanh: that ratio is 1 in
+        # fp32 as well; ssp(1e-8) is below fp32's resolution next to ln 2, in any fp32 implementation)
+        x[3, 6:9] = 0.0
+    w1, w2 = torch.randn_like(x), torch.randn_like(x)
+    res = []
+    for mod, dev, dt in ((o, "cpu", torch.float64), (h, device, torch.float32)):
+        xx = x.to(dev, dt).requires_grad_(True)
+        gg = w1.to(dev, dt).requires_grad_(True)
+        (g1,) = torch.autograd.grad(mod(xx), [xx], gg, create_graph=True)
+        loss = (g1 * w2.to(dev, dt)).sum() + g1.square().sum()
+        res.append(torch.autograd.grad(loss, [xx, gg]))
+    for a, b in zip(res[1], res[0]):
+        assert rel(a, b) < TOL
+
+
+@pytest.mark.parametrize("graphs", [1, 3])
+def test_cell_gradient_second_order_vs_oracle(device, graphs):
+    """The gradient with respect to the periodic cell is itself differentiable (eigenn/nn/_nequip.py:236-262 under
+    create_graph=True): d/d(pos, cell) of a function of dE/dcell and dE/dpos, single-cell and batched-cell branches."""
+    import matten_amd.nn as H
+    from matten_amd import keys as K
+    from matten_amd.data.crystal import collate, make_crystal
+    from oracle import eigenn_ref as R
+
+    batch = collate([make_crystal(2, 2.6, seed=80 + g) for g in range(graphs)])
+    E = batch[K.EDGE_INDEX].shape[1]
+    g = torch.Generator().manual_seed(graphs)
+    go1, go2 = torch.randn(E, 9, generator=g), torch.randn(E, 8, generator=g)
+    wc, wp = torch.randn(3 * graphs, 3, generator=g), torch.randn(batch[K.POSITIONS].shape, generator=g)
+    outs = []
+    for mod, dev, dt in ((R, "cpu", torch.float64), (H, device, torch.float32)):
+        sh = mod.SphericalHarmonicEdgeAttrs(2).to(dev)
+        rb = mod.RadialBasisEdgeEncoding(basis_kwargs={"num_basis": 8, "r_max": 5.0}, cutoff_kwargs={"r_max": 5.0}).to(dev).to(dt)
+        data = {k: (v.to(dt) if v.is_floating_point() else v).to(dev) for k, v in batch.items() if k in (K.POSITIONS, K.CELL, K.EDGE_INDEX, K.EDGE_CELL_SHIFT, K.BATCH)}
+        data[K.POSITIONS].requires_grad_(True)
+        data[K.CELL].requires_grad_(True)
+        pos, cell = data[K.POSITIONS], data[K.CELL]
+        data = rb(sh(data))
+        e = (data[K.EDGE_ATTRS] * go1.to(dev, dt)).sum() + (data[K.EDGE_EMBEDDING] * go2.to(dev, dt)).sum()
+        gp, gc = torch.autograd.grad(e, [pos, cell], create_graph=True)
+        loss = (gc * wc.to(dev, dt)).sum() + 0.5 * gc.square().sum() + (gp * wp.to(dev, dt)).sum()
+        outs.append(torch.autograd.grad(loss, [pos, cell]))
+    for a, b in zip(outs[1], outs[0]):
+        assert rel(a, b) < TOL
