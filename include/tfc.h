@@ -16,8 +16,8 @@
  *     pipeline (eigenn/data/_dtype.py:3-4), int32 for the orderings this library builds.
  *   - the library never allocates or frees device memory inside a compute call: scratch comes
  *     in through `workspace` arguments whose size the *_workspace_* functions report.  Only
- *     tfc_conv_plan_create() allocates (small constant tables) and tfc_conv_plan_destroy()
- *     frees them.
+ *     tfc_conv_plan_create() and tfc_conv_plan_set_out_blocks() allocate (small constant tables
+ *     of the plan) and tfc_conv_plan_destroy() frees them.
  *   - all launches are asynchronous on the caller's `stream` (a hipStream_t passed as void*,
  *     0 = the null stream).  No call synchronises the host.  Plans are immutable after
  *     creation, so calls are re-entrant across host threads and streams; the only global

@@ -59,6 +59,15 @@ def _f32(t: torch.Tensor, name: str) -> torch.Tensor:
     return t.contiguous()
 
 
+def _tracked(t):
+    """Contiguous, made HERE - outside the autograd.Function - so that autograd sees the copy: the functions
+    save their inputs for a differentiable backward (create_graph=True), and a copy made inside Function.forward would
+    be cut off from the caller's graph (second-order terms through a non-contiguous input would vanish)."""
+    if t is None or t.is_contiguous():
+        return t
+    return t.contiguous()  # (dtype and device are checked, not converted, by _f32)
+
+
 # ======================================================================================
 # edge ordering
 # ======================================================================================
@@ -225,6 +234,24 @@ def check_edge_orderings(wait: bool = False):
                          "from the convolution of an EARLIER batch, whose results are invalid")
 
 
+def _flush_edge_checks_at_exit():
+    """The verdict on the LAST batch has no later ordering to surface it: report it when the interpreter exits (training
+    and prediction loops should call check_edge_orderings(wait=True) at the end of an epoch / a predict call)."""
+    try:
+        check_edge_orderings(wait=True)
+    except IndexError as ex:
+        import sys
+
+        print(f"matten_amd: {ex}", file=sys.stderr)
+    except Exception:
+        pass
+
+
+import atexit as _atexit
+
+_atexit.register(_flush_edge_checks_at_exit)
+
+
 def edge_ordering(edge_index: torch.Tensor, n_nodes: int) -> EdgeOrdering:
     """Ordering for this edge_index tensor, built once and shared by all layers (and by
     forward and backward) that see the same tensor object."""
@@ -309,7 +336,10 @@ def _conv_fwd_raw(x, y, w, plan: ConvPlan, ordering, fwd_rows, n_out: int, scale
     if rp.numel() != n_out + 1:
         raise ValueError("conv: ordering does not match the number of output rows")
     out = torch.empty(n_out, plan.d_out, dtype=torch.float32, device=x.device)
-    out_t = torch.empty(n_out * plan.d_out, dtype=torch.float32, device=x.device) if plan.out_blocks and n_out else None
+    # the channel-contiguous second copy serves the o3.Linear on NODE rows that follows; the per-edge route (n_out = E:
+    # 1.4 GB at the last config-3 layer) has no such consumer
+    per_edge = fwd_rows is ordering._edge_rows
+    out_t = torch.empty(n_out * plan.d_out, dtype=torch.float32, device=x.device) if plan.out_blocks and n_out and not per_edge else None
     M = ordering.m_matrices(plan, y, fwd_rows)
     _lib.check(
         _lib.lib().tfc_conv_fwd_m_t(
@@ -333,7 +363,8 @@ def _conv_bwd_raw(gout, x, y, w, plan: ConvPlan, ordering, bwd_rows, scale: floa
     h = plan.handle(x.device)
     M = ordering.m_matrices(plan, y, bwd_rows)
     dyp = torch.empty(int(L.tfc_conv_dy_floats(h, E)), dtype=torch.float32, device=x.device) if need_dy else None
-    dx_t = torch.empty(x.numel(), dtype=torch.float32, device=x.device) if plan.out_blocks and x.numel() else None
+    per_edge = eid is nbr  # (conv(per_edge=True) passes the edge ids in both places)
+    dx_t = torch.empty(x.numel(), dtype=torch.float32, device=x.device) if plan.out_blocks and x.numel() and not per_edge else None
     _lib.check(
         L.tfc_conv_bwd_m_t(
             h, _ptr(x), _ptr(M), _ptr(w), _ptr(gout), _ptr(rp), _ptr(eid), _ptr(nbr),
@@ -407,6 +438,7 @@ class _ConvBwdFn(torch.autograd.Function):
 def conv(x, y, w, plan: ConvPlan, ordering: EdgeOrdering, scale: float = 1.0, per_edge: bool = False):
     """out[n] = scale * sum_{e -> n} TP_uvu(x[sender(e)], y[e]; w[e]); `per_edge=True`
     returns the un-summed messages [E, d_out] instead (each edge is its own row)."""
+    x, y, w = _tracked(x), _tracked(y), _tracked(w)
     if per_edge:
         rps, eids, _ = ordering.by_src  # backward gathers the gradient row of the edge itself
         return _ConvFn.apply(x, y, w, plan, ordering, ordering.per_edge(), (rps, eids, eids), ordering.n_edges, scale)
@@ -1098,7 +1130,7 @@ class _LinearBwdFn(torch.autograd.Function):
 
 
 def linear(x, weight, spec: LinearSpec):
-    return _LinearFn.apply(x, weight, spec)
+    return _LinearFn.apply(_tracked(x), _tracked(weight), spec)
 
 
 # ------------------------------------------------------------------ radial FullyConnectedNet
@@ -1270,7 +1302,7 @@ def self_ordering(n: int, device) -> "EdgeOrdering":
 
 
 def radial_mlp(x, weights: Sequence[torch.Tensor], act_cst: float, pre=None):
-    return _RadialMlpFn.apply(x, act_cst, pre, *weights)
+    return _RadialMlpFn.apply(_tracked(x), act_cst, pre, *[_tracked(w) for w in weights])
 
 
 def radial_mlp_precompute(x, weights: Sequence[torch.Tensor], act_cst: float):
@@ -1626,6 +1658,7 @@ def fctp(x, a, weight, spec: FctpSpec, base: Optional[torch.Tensor] = None, low_
     """FullyConnectedTensorProduct(x, a) with scalar `a`; when `base` is given the result is
     accumulated into it in place (out = base + fctp), saving the separate add.  `low_rank`: take the
     shorter contraction when the rows of `a` are copies of a few distinct rows (attr_factors)."""
+    x, a, weight = _tracked(x), _tracked(a), _tracked(weight)
     factors = attr_factors(a, classes) if low_rank else None
     return _FctpFn.apply(x, a, weight, spec, base, factors)
 
@@ -1716,7 +1749,7 @@ class _GateBwdFn(torch.autograd.Function):
 
 
 def gate(x, spec: GateSpec):
-    return _GateFn.apply(x, spec)
+    return _GateFn.apply(_tracked(x), spec)
 
 
 class _NormActFn(torch.autograd.Function):
@@ -1779,4 +1812,4 @@ class _NormActBwdFn(torch.autograd.Function):
 def norm_activation(x, spec: GateSpec, eps_squared: float = 0.0, normalize: bool = True):
     """e3nn.nn.NormActivation on [N, d] rows (tfc_norm_act_fwd/bwd); `spec.segs`: one
     (in_off, in_off, mul, 2l+1, -1, act, 1.0) per block."""
-    return _NormActFn.apply(x, spec, float(eps_squared), bool(normalize))
+    return _NormActFn.apply(_tracked(x), spec, float(eps_squared), bool(normalize))
