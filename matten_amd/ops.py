@@ -68,6 +68,24 @@ def _tracked(t):
     return t.contiguous()  # (dtype and device are checked, not converted, by _f32)
 
 
+# Everything the ops keep BETWEEN calls that holds device tensors lives in a dict made by _tensor_cache(): one registry,
+# walked by clear_caches() - a cache added later cannot be forgotten there (a tensor freed inside a HIP-graph capture
+# that an earlier eager step used on another stream makes the allocator record an event mid-capture, and
+# hipStreamEndCapture then fails).  The caches are process-global on purpose: every entry is keyed by the identity of
+# the tensor it was derived from (address / object id AND version counter, with the source held alive so that the
+# address cannot be reused), a miss always falls back to recomputing, and workspaces are keyed by (device, stream), on
+# which launches are ordered - so two host threads can at worst evict each other's entries, never read a wrong one.
+# What the keys cannot see is a write through `.data`, which does not bump the version counter: do not use it on
+# tensors handed to these ops.
+_TENSOR_CACHES: "list[dict]" = []
+
+
+def _tensor_cache() -> dict:
+    d: dict = {}
+    _TENSOR_CACHES.append(d)
+    return d
+
+
 # ======================================================================================
 # edge ordering
 # ======================================================================================
@@ -192,7 +210,7 @@ class EdgeOrdering:
             raise IndexError("edge_index contains node ids outside [0, n_nodes)")
 
 
-_ORDER_CACHE: "dict[int, tuple]" = {}
+_ORDER_CACHE: "dict[int, tuple]" = _tensor_cache()
 # TFC_VALIDATE_EDGES: "deferred" (default; see EdgeOrdering.__init__), "sync" (raise at once: one host
 # synchronisation per new edge_index tensor) or "off".  The reference raises IndexError from its gather when
 # an edge names a node outside [0, N); here such edges are dropped from the groupings and flagged.
@@ -207,12 +225,8 @@ def clear_caches():
     default stream would record an allocator event on that stream in the middle of the capture."""
     torch.cuda.synchronize()
     check_edge_orderings(wait=True)
-    _ORDER_CACHE.clear()
-    _SELF_ORDERINGS.clear()
-    _TRANSPOSED.clear()
-    _ATTR_FACTORS.clear()
-    _ATTR_CLASSES.clear()
-    _GEMM_WS.clear()
+    for cache in _TENSOR_CACHES:
+        cache.clear()
 
 
 def check_edge_orderings(wait: bool = False):
@@ -843,7 +857,7 @@ def _ws_floats(m: int, n: int, k: int) -> int:
     return int(_lib.lib().tfc_gemm_workspace_floats(m, n, k))
 
 
-_GEMM_WS: "dict[tuple, torch.Tensor]" = {}
+_GEMM_WS: "dict[tuple, torch.Tensor]" = _tensor_cache()
 
 
 def _gemm_workspace(n_floats: int) -> torch.Tensor:
@@ -948,7 +962,7 @@ def _gemm_waves(items):
         _gemm_group(group)
 
 
-_TRANSPOSED: "dict[tuple, tuple]" = {}
+_TRANSPOSED: "dict[tuple, tuple]" = _tensor_cache()
 
 
 @functools.lru_cache(maxsize=256)
@@ -1289,7 +1303,7 @@ def radial_mlp_general(x, weights: Sequence[torch.Tensor], act_cst: float, act_i
     return _radial_mlp_composite(x, list(weights), act_cst, act_id)
 
 
-_SELF_ORDERINGS: "dict[tuple, tuple]" = {}
+_SELF_ORDERINGS: "dict[tuple, tuple]" = _tensor_cache()
 
 
 def self_ordering(n: int, device) -> "EdgeOrdering":
@@ -1382,9 +1396,9 @@ def _fctp_bwd(n, x, a, d_a, weight, gt, spec, ins_list, dx=None, dw=None, da=Non
 
 
 ROUTE_COUNTS = {"fctp_dense": 0, "fctp_low_rank": 0}  # forward calls per self-connection route (read by tests)
-_ATTR_FACTORS: "dict[tuple, tuple]" = {}
-_ATTR_CLASSES: "dict[tuple, tuple]" = {}
-_HASH_COEF: "dict[tuple, torch.Tensor]" = {}
+_ATTR_FACTORS: "dict[tuple, tuple]" = _tensor_cache()
+_ATTR_CLASSES: "dict[tuple, tuple]" = _tensor_cache()
+_HASH_COEF: "dict[tuple, torch.Tensor]" = _tensor_cache()
 
 
 class AttrFactors(NamedTuple):

@@ -224,3 +224,16 @@ def test_attr_factors_host_logic(with_hint):
         nan_rows = a.clone()
         nan_rows[3, 0] = float("nan")
         assert ops.attr_factors(nan_rows) is None  # NaN rows never verify as copies
+
+
+def test_every_cache_of_the_ops_is_registered():
+    """ops.clear_caches() walks one registry; a module-level dict that is not in it must be on the short list of
+    tables that hold no device tensors (a forgotten cache brings the graph-capture failure back)."""
+    from matten_amd import ops
+
+    registered = {id(d) for d in ops._TENSOR_CACHES}
+    no_tensors = {"_FCTP_WS", "_SIDE_STREAMS"}  # byte counts; stream objects
+    for name, val in vars(ops).items():
+        if isinstance(val, dict) and name.startswith("_") and name.upper() == name and not name.startswith("__"):
+            assert id(val) in registered or name in no_tensors, name
+    assert len(registered) >= 7

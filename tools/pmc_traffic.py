@@ -37,5 +37,12 @@ for kern in ("tfc_conv_fwd_kernel", "tfc_conv_bwd_kernel"):
         per_grid[str(g)] = {"fetch_bytes": fbytes, "write_bytes": wbytes, "launches_sampled": len(xs)}
     tot = sum(v["fetch_bytes"] + v["write_bytes"] for v in per_grid.values())
     res["kernels"][kern] = {"per_grid": per_grid, "avg_bytes_per_launch": tot / max(len(per_grid), 1)}
+# the build the counters were collected on (bench.py puts the same hash on its line)
+try:
+    import hashlib
+    lib = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "matten_amd", "libtfc.so")
+    res["lib_sha256_16"] = hashlib.sha256(open(lib, "rb").read()).hexdigest()[:16]
+except OSError:
+    res["lib_sha256_16"] = None
 json.dump(res, open(dst, "w"), indent=1)
 print(json.dumps(res, indent=1))

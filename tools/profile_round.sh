@@ -10,7 +10,7 @@ root=$GRAFT_REPO_ROOT
 out=$root/gpurun_out/prof_$tag
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
-BENCH="python3 $root/bench.py --steps 10 --warmup 3 --no-cpu-baseline --workload $wl"
+BENCH="python3 $root/bench.py --steps 10 --warmup 3 --no-cpu-baseline --fresh 0 --workload $wl"
 timeout -s KILL 200 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -- $BENCH > $out/bench_under_rocprof.json 2> $out/trace.log
 echo "trace done" >> $out/progress
 timeout -s KILL 150 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/fetch -- $BENCH > $out/fetch.log 2>&1
@@ -24,4 +24,7 @@ timeout -k 10 300 python3 $root/bench.py --steps 30 --warmup 8 --workload $wl > 
 echo "bench done" >> $out/progress
 # keep only what the summaries read (the merge back is capped at 64 MiB)
 find $out -name "*.csv" ! -name "*kernel_trace.csv" ! -name "*kernel_stats.csv" ! -name "*counter_collection.csv" -delete
+python3 $root/tools/pmc_traffic.py $out $out/pmc_traffic_$wl.json > /dev/null 2>&1 || true
+python3 $root/tools/prof_summary.py $out/trace > $out/kernel_by_grid.txt 2>&1 || true
+find $out -name "*counter_collection.csv" -delete
 du -sh $out
