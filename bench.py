@@ -161,17 +161,20 @@ def fresh_batch_timing(args, wl, rank, device, batch0, compute, bucket, sync, di
     padded = [pad_null_edges(b, e_pad) for b in raws]
     if len({int(b[K.POSITIONS].shape[0]) for b in padded}) != 1:
         raise RuntimeError("fresh batches differ in their atom counts")
-    static = {k: v.detach().clone() for k, v in padded[0].items()}
+    from matten_amd.graphs import PackedBatch
+
+    packed_static = PackedBatch(padded[0])  # every tensor of the batch is a view into one buffer: copy-in is ONE copy
+    packed = [PackedBatch(b, like=packed_static) for b in padded]
+    static = packed_static.tensors
 
     def copy_in(i):
-        with torch.no_grad():
-            for k, v in padded[i % nb].items():
-                static[k].copy_(v)
+        packed_static.load(packed[i % nb])
 
     replay = GraphedStep(lambda: compute(static), rebuild_topology=True)
 
     def gstep(i):
-        copy_in(i)
+        if not os.environ.get("TFC_BENCH_FRESH_NOCOPY"):  # (diagnosis: the rebuilt-topology graph alone)
+            copy_in(i)
         g, grads = replay()
         bucket.all_reduce_mean(grads=grads)
 
@@ -193,6 +196,13 @@ def fresh_batch_timing(args, wl, rank, device, batch0, compute, bucket, sync, di
         if dist is not None:
             dist.all_reduce(el, op=dist.ReduceOp.MAX)
         out[name] = float(el.item()) / args.steps * 1e3
+        if name == "ms_per_step":  # what the host spends per step on the copy-in and the graph launch (queue empty at the start)
+            sync()
+            t0 = time.perf_counter()
+            for i in range(8):
+                fn(i)
+            out["host_ms_per_launch"] = (time.perf_counter() - t0) / 8 * 1e3
+            sync()
     out["launch"] = "hip_graph_replay, topology rebuilt in the graph, batch copied in"
     return out
 

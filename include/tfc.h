@@ -460,6 +460,17 @@ int tfc_fctp_bwd(const tfc_fctp_ins* ins, int32_t n_ins, const float* x, const f
 int tfc_fctp_class_rows(const float* part, int32_t n_parts, int32_t r, int32_t d_a, const float* inv_count,
                         const int64_t* cls, int64_t n_rows, float* da, tfc_stream_t stream);
 
+/* The class table of node attributes that are rows of a per-class table (eigenn/nn/embedding.py:59-75: NODE_ATTRS =
+ * embedding(species), so the classes are the species indices and their number is known): in one call, with no host
+ * synchronisation (it runs inside captured steps),
+ *     onehot[n, s]  = 1 if cls[n] == s else 0          [n_rows, r] fp32, r >= n_classes a multiple of 4
+ *     rep_idx[s]    = first row of class s (0 if none), rep_mask[s] = 1 if the class has a row else 0
+ *     inv_count[s]  = 1 / max(rows in class s, 1)
+ * rows with a class outside [0, n_classes) get a zero one-hot row and count for nothing.  `work`: 2 r int32 of device
+ * memory (overwritten).  Counting uses integer atomics: the result does not depend on scheduling. */
+int tfc_class_table(const int64_t* cls, int64_t n_rows, int32_t n_classes, int32_t r, int32_t* work, float* onehot,
+                    int64_t* rep_idx, float* rep_mask, float* inv_count, tfc_stream_t stream);
+
 /* Channel-contiguous copy of feature rows, for the operands of the dense contractions above:
  * e3nn stores a block as [mul][2l+1] (eigenn feature layout, see the conventions at the top), which
  * gives the contraction index u of o3.Linear / FullyConnectedTensorProduct the stride 2l+1; block b

@@ -99,6 +99,79 @@ __global__ __launch_bounds__(256) void tfc_class_rows_kernel(const float* __rest
     }
 }
 
+typedef float floatx4 __attribute__((ext_vector_type(4)));
+
+// ---- class table of a labelling with a known number of classes (tfc_class_table) --------------------------------
+// work[0..r) = first row of each class (INT_MAX: none yet), work[r..2r) = rows in the class; integer atomics, so the
+// result does not depend on the order in which the rows arrive
+__global__ __launch_bounds__(64) void tfc_class_init_kernel(int* __restrict__ work, int r) {
+    const int s = threadIdx.x + blockIdx.x * blockDim.x;
+    if (s < r) {
+        work[s] = 0x7fffffff;
+        work[r + s] = 0;
+    }
+}
+
+// (per workgroup the first rows and the counts are gathered in LDS - up to CLASS_LDS classes - and only then merged
+// into `work`: a few thousand rows on a handful of classes would otherwise queue on as many global addresses)
+constexpr int CLASS_LDS = 256;
+
+__global__ __launch_bounds__(256) void tfc_class_scan_kernel(const int64_t* __restrict__ cls, long n_rows, int n_classes, int r,
+                                                             int* __restrict__ work, float* __restrict__ onehot) {
+    __shared__ int s_first[CLASS_LDS];
+    __shared__ int s_count[CLASS_LDS];
+    const bool local = n_classes <= CLASS_LDS;
+    if (local) {
+        for (int s = threadIdx.x; s < n_classes; s += blockDim.x) {
+            s_first[s] = 0x7fffffff;
+            s_count[s] = 0;
+        }
+        __syncthreads();
+    }
+    for (long n = (long)blockIdx.x * blockDim.x + threadIdx.x; n < n_rows; n += (long)gridDim.x * blockDim.x) {
+        const long c = cls[n];
+        const bool ok = c >= 0 && c < n_classes;
+        float* row = onehot + n * r;
+        for (int s = 0; s < r; s += 4) {
+            floatx4 v;
+            v[0] = (ok && c == s) ? 1.f : 0.f;
+            v[1] = (ok && c == s + 1) ? 1.f : 0.f;
+            v[2] = (ok && c == s + 2) ? 1.f : 0.f;
+            v[3] = (ok && c == s + 3) ? 1.f : 0.f;
+            *reinterpret_cast<floatx4*>(row + s) = v;
+        }
+        if (ok) {
+            if (local) {
+                atomicMin(s_first + c, (int)n);
+                atomicAdd(s_count + c, 1);
+            } else {
+                atomicMin(work + c, (int)n);
+                atomicAdd(work + r + c, 1);
+            }
+        }
+    }
+    if (local) {
+        __syncthreads();
+        for (int s = threadIdx.x; s < n_classes; s += blockDim.x) {
+            if (s_count[s] > 0) {
+                atomicMin(work + s, s_first[s]);
+                atomicAdd(work + r + s, s_count[s]);
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(64) void tfc_class_finish_kernel(const int* __restrict__ work, int r, int64_t* __restrict__ rep_idx,
+                                                              float* __restrict__ rep_mask, float* __restrict__ inv_count) {
+    const int s = threadIdx.x + blockIdx.x * blockDim.x;
+    if (s < r) {
+        const int first = work[s], cnt = work[r + s];
+        rep_idx[s] = cnt > 0 ? (int64_t)first : 0;
+        rep_mask[s] = cnt > 0 ? 1.f : 0.f;
+        inv_count[s] = 1.f / (float)(cnt > 0 ? cnt : 1);
+    }
+}
+
 }  // namespace
 
 extern "C" int tfc_fctp_class_rows(const float* part, int32_t n_parts, int32_t r, int32_t d_a, const float* inv_count,
@@ -111,6 +184,26 @@ extern "C" int tfc_fctp_class_rows(const float* part, int32_t n_parts, int32_t r
     TfcProfScope prof("tfc_class_rows_kernel", stream);
     tfc_class_rows_kernel<<<grid, 256, 0, stream>>>(part, n_parts, r, d_a, inv_count, cls, (long)n_rows, da);
     TFC_LAUNCH_CHECK("tfc_class_rows_kernel");
+    return TFC_OK;
+}
+
+extern "C" int tfc_class_table(const int64_t* cls, int64_t n_rows, int32_t n_classes, int32_t r, int32_t* work, float* onehot,
+                               int64_t* rep_idx, float* rep_mask, float* inv_count, tfc_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    TFC_REQUIRE(n_rows >= 0 && n_rows < 0x7fffffffL && n_classes > 0 && r >= n_classes && r % 4 == 0, TFC_EINVAL,
+                "tfc_class_table: need 0 < n_classes <= r, r a multiple of 4, fewer than 2^31 rows");
+    TFC_REQUIRE(work && rep_idx && rep_mask && inv_count && (n_rows == 0 || (cls && onehot)), TFC_EINVAL,
+                "tfc_class_table: null tensor");
+    TfcProfScope prof("tfc_class_table", stream);
+    tfc_class_init_kernel<<<(r + 63) / 64, 64, 0, stream>>>(work, r);
+    TFC_LAUNCH_CHECK("tfc_class_init_kernel");
+    if (n_rows > 0) {
+        const int grid = (int)std::min<long>((n_rows + 255) / 256, 2048);
+        tfc_class_scan_kernel<<<grid, 256, 0, stream>>>(cls, (long)n_rows, n_classes, r, work, onehot);
+        TFC_LAUNCH_CHECK("tfc_class_scan_kernel");
+    }
+    tfc_class_finish_kernel<<<(r + 63) / 64, 64, 0, stream>>>(work, r, rep_idx, rep_mask, inv_count);
+    TFC_LAUNCH_CHECK("tfc_class_finish_kernel");
     return TFC_OK;
 }
 

@@ -1439,16 +1439,20 @@ def _rep_rows(rep: torch.Tensor, n: int, r: int):
 
 
 def _class_structure_static(labels: torch.Tensor, u: int):
-    """_class_structure for labels known to lie in [0, u): no host synchronisation (classes without a member get a
-    zero row and weight 1)."""
+    """_class_structure for labels known to lie in [0, u): one library call (tfc_class_table), no host
+    synchronisation - it runs inside captured steps (classes without a member get a zero row and weight 1)."""
     n = labels.shape[0]
     r = max(4, (u + 3) // 4 * 4)
-    ar = torch.arange(n, device=labels.device)
-    rep = torch.full((u,), n, dtype=torch.int64, device=labels.device)
-    rep.scatter_reduce_(0, labels, ar, reduce="amin")
-    # (comparison, not indexed assignment: nothing here may synchronise or stage a host scalar - it runs inside captures)
-    Cm = (labels.unsqueeze(1) == torch.arange(r, device=labels.device).unsqueeze(0)).to(torch.float32)
-    return labels, _rep_rows(rep, n, r), Cm, u, r, 1.0 / Cm.sum(0).clamp_min(1.0)
+    dev = labels.device
+    labels = labels.contiguous()
+    work = torch.empty(2 * r, dtype=torch.int32, device=dev)
+    Cm = torch.empty(n, r, dtype=torch.float32, device=dev)
+    idx = torch.empty(r, dtype=torch.int64, device=dev)
+    mask = torch.empty(r, 1, dtype=torch.float32, device=dev)
+    inv_count = torch.empty(r, dtype=torch.float32, device=dev)
+    _lib.check(_lib.lib().tfc_class_table(_ptr(labels), n, int(u), r, _ptr(work), _ptr(Cm), _ptr(idx), _ptr(mask), _ptr(inv_count),
+                                          _stream()))
+    return labels, (idx, mask), Cm, u, r, inv_count
 
 
 def attr_factors(a: torch.Tensor, classes: Optional[torch.Tensor] = None):

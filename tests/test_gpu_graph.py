@@ -74,7 +74,11 @@ def test_replay_takes_new_batches_by_copy_in(device):
     model = Stack("hip", cfg).to(device)
     params = list(model.parameters())
     n_graphs = cfg["graphs"]
-    static = {k: v.detach().clone() for k, v in batches[0].items()}  # the buffers the graph reads
+    from matten_amd.graphs import PackedBatch
+
+    packed_static = PackedBatch(batches[0])  # the buffers the graph reads: views into one flat buffer
+    packed = [PackedBatch(b, like=packed_static) for b in batches]
+    static = packed_static.tensors
 
     def run(b):
         for p in params:
@@ -100,9 +104,7 @@ def test_replay_takes_new_batches_by_copy_in(device):
 
     replay = GraphedStep(lambda: run(static), rebuild_topology=True)
     for i in (1, 2, 0, 2):
-        with torch.no_grad():
-            for k, v in batches[i].items():
-                static[k].copy_(v)
+        packed_static.load(packed[i])  # one copy for the whole batch
         got = snapshot(replay())
         ref = snapshot(run(batches[i]))
         torch.cuda.synchronize()

@@ -1191,3 +1191,45 @@ def test_fctp_class_rows_entry_point(device):
     ref[6] = 0
     assert torch.equal(da, ref)
     assert _lib.lib().tfc_fctp_class_rows(ops._ptr(part), 0, r, d_a, ops._ptr(inv_count), ops._ptr(cls), n, ops._ptr(da), ops._stream()) < 0
+
+
+def test_class_table_matches_its_definition(device):
+    """tfc_class_table (the per-batch class structure of the self connection's low-rank route): one-hot rows, first
+    row and inverse size of each class, with an empty class, padding classes and a label out of range."""
+    from matten_amd import ops
+
+    g = torch.Generator().manual_seed(5)
+    n, u = 1000, 6
+    labels = torch.randint(0, u, (n,), generator=g)
+    labels[labels == 4] = 1  # class 4 has no member
+    labels[:3] = torch.tensor([5, 2, 2])
+    inv, (idx, mask), Cm, u_out, r, inv_count = ops._class_structure_static(labels.to(device), u)
+    assert (u_out, r) == (u, 8) and Cm.shape == (n, r)
+    ref_C = torch.zeros(n, r)
+    ref_C[torch.arange(n), labels] = 1.0
+    assert torch.equal(Cm.cpu(), ref_C)
+    counts = ref_C.sum(0)
+    assert torch.equal(inv_count.cpu(), 1.0 / counts.clamp_min(1.0))
+    assert torch.equal(mask.cpu().reshape(-1), (counts > 0).float())
+    for s in range(r):
+        want = int((labels == s).nonzero()[0]) if counts[s] > 0 else 0
+        assert int(idx[s]) == want, s
+    # a label outside [0, u): zero row, counted nowhere
+    bad = labels.clone()
+    bad[7] = 6
+    bad[8] = -1
+    _, (idx2, mask2), Cm2, _, _, inv2 = ops._class_structure_static(bad.to(device), u)
+    assert Cm2[7].abs().sum().item() == 0 and Cm2[8].abs().sum().item() == 0
+    ref2 = torch.zeros(n, r)
+    ok = (bad >= 0) & (bad < u)
+    ref2[torch.arange(n)[ok], bad[ok]] = 1.0
+    assert torch.equal(Cm2.cpu(), ref2)
+    assert torch.equal(inv2.cpu(), 1.0 / ref2.sum(0).clamp_min(1.0))
+    # more classes than the kernel gathers per workgroup: the direct route
+    big = torch.randint(0, 300, (5000,), generator=g)
+    _, (idx3, mask3), Cm3, _, r3, inv3 = ops._class_structure_static(big.to(device), 300)
+    ref3 = torch.zeros(5000, r3)
+    ref3[torch.arange(5000), big] = 1.0
+    assert torch.equal(Cm3.cpu(), ref3) and torch.equal(inv3.cpu(), 1.0 / ref3.sum(0).clamp_min(1.0))
+    first = torch.full((r3,), 5000, dtype=torch.int64).scatter_reduce_(0, big, torch.arange(5000), reduce="amin")
+    assert torch.equal(idx3.cpu(), torch.where(first < 5000, first, torch.zeros_like(first)))

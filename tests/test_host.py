@@ -237,3 +237,30 @@ def test_every_cache_of_the_ops_is_registered():
         if isinstance(val, dict) and name.startswith("_") and name.upper() == name and not name.startswith("__"):
             assert id(val) in registered or name in no_tensors, name
     assert len(registered) >= 7
+
+
+def test_packed_batch_is_one_buffer_and_refuses_another_layout():
+    import torch
+
+    from matten_amd.graphs import PackedBatch
+
+    g = torch.Generator().manual_seed(3)
+    def batch(e):
+        return {"pos": torch.randn(5, 3, generator=g), "edge_index": torch.randint(0, 5, (2, e), generator=g),
+                "cell": torch.randn(1, 3, 3, generator=g), "flag": torch.tensor([1, 0, 1], dtype=torch.uint8)}
+
+    a, b = batch(7), batch(7)
+    static = PackedBatch(a)
+    for k, v in a.items():
+        assert torch.equal(static.tensors[k], v) and static.tensors[k].dtype == v.dtype
+        assert static.tensors[k].data_ptr() % 16 == 0
+    before = {k: (v.data_ptr(), v._version) for k, v in static.tensors.items()}
+    static.load(PackedBatch(b, like=static))
+    for k, v in b.items():
+        assert torch.equal(static.tensors[k], v)
+        assert static.tensors[k].data_ptr() == before[k][0]       # same addresses: a captured step keeps reading them
+        assert static.tensors[k]._version != before[k][1]         # and the version-keyed caches of the eager path miss
+    import pytest
+
+    with pytest.raises(ValueError, match="differ"):
+        PackedBatch(batch(8), like=static)
