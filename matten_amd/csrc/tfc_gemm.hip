@@ -24,6 +24,7 @@
 #include "tfc_common.h"
 
 #include <algorithm>
+#include <cstring>
 #include <cstdlib>
 #include <vector>
 
@@ -31,8 +32,14 @@ namespace {
 
 typedef float floatx16 __attribute__((ext_vector_type(16)));
 
-constexpr int BK = 16;
-constexpr int KT = 8;  // K tiles whose k offsets are evaluated together
+constexpr int BK = 16;   // K tile (and the unit the host counts K ranges in)
+// (The staging code and the kernel take the K tile as a template parameter, BKT.  32 was measured in round 3, all
+// instantiations correct: with every 64 x 64 / 128 x 64 tile at 32 the radial network's weight gradient gains 10 %
+// and o3.Linear loses 20 % (config 4: 0.29 -> 0.23 of the matrix peak; 90 - 150 VGPRs and 43 KB of LDS instead of
+// 40 - 44 and 25 KB, three workgroups per CU instead of four), step unchanged; with only the weight gradient of the
+// radial network at 32 the step is unchanged too (config 3 / 4 / 5: 2.71 / 39.0 / 3.84 against 2.70 / 39.2 / 3.81 ms).
+// Every instantiation therefore runs at 16.)
+constexpr int KOFF = 128;  // k offsets evaluated together (KOFF / BKT tiles at a time)
 constexpr int MAXP = 8;  // problems per launch (the group is passed by value as kernel argument)
 
 struct Map {
@@ -92,7 +99,7 @@ __device__ __forceinline__ float epilogue_apply(const Problem& P, float acc, lon
 // load() only ISSUES the global loads; the product of the two factors and the zeroing of the K
 // tail happen in store(), after the MFMAs of the current tile, so that nothing waits on the loads
 // while they are in flight.
-template <int BX, bool KFAST, bool HAS2, bool VEC, int REP = 1>
+template <int BX, bool KFAST, bool HAS2, bool VEC, int REP = 1, int BK = 16>
 struct Operand {
     static constexpr int NE = BX * BK / 256;  // elements per thread
     static constexpr int S = BX + 4;          // LDS row stride
@@ -150,10 +157,11 @@ struct Operand {
 // v of the self connection) and the SECOND contiguous; the host swaps the factors into that order
 // and selects this variant only when the maps, the base pointers and the extents guarantee
 // aligned, in-bounds groups (flags_of()).
-template <int BX, bool KFAST, bool HAS2, int REP>
-struct Operand<BX, KFAST, HAS2, true, REP> {
+template <int BX, bool KFAST, bool HAS2, int REP, int BK>
+struct Operand<BX, KFAST, HAS2, true, REP, BK> {
     static constexpr int NV = BX * BK / 1024;  // groups per thread
     static constexpr int S = BX + 4;
+    static constexpr int KQ = BK / 4;          // 16-byte groups along k per row
     float4 v[NV][REP];
     float s[HAS2 ? NV : 1][REP];
 
@@ -166,12 +174,12 @@ struct Operand<BX, KFAST, HAS2, true, REP> {
                                          long rs1, long rs2) {
         // (p, roff, ko) address the broadcast factor when HAS2, the only factor otherwise
         if (KFAST) {
-            const int kq = t & 3;  // k = 4 kq .. 4 kq + 3
+            const int kq = t % KQ;  // k = 4 kq .. 4 kq + 3
             const long o = ko[4 * kq];
             const long o2 = HAS2 ? ko2[4 * kq] : 0;
 #pragma unroll
             for (int q = 0; q < NV; ++q) {
-                const int x = (t >> 2) + 64 * q;
+                const int x = t / KQ + (256 / KQ) * q;
                 if (HAS2) {
                     const float* b1 = p + roff[x] + o;
                     const float* b2 = p2 + roff2[x] + o2;
@@ -224,7 +232,7 @@ struct Operand<BX, KFAST, HAS2, true, REP> {
                 }
             }
             if (KFAST) {
-                const int k = 4 * (t & 3), x = (t >> 2) + 64 * q;
+                const int k = 4 * (t % KQ), x = t / KQ + (256 / KQ) * q;
                 if (k_left < BK) {  // K tail (last tile only)
                     a.x = k + 0 < k_left ? a.x : 0.f;
                     a.y = k + 1 < k_left ? a.y : 0.f;
@@ -244,8 +252,9 @@ struct Operand<BX, KFAST, HAS2, true, REP> {
     }
 };
 
-template <int TM, int TN, int REP, bool A_KFAST, bool B_KFAST, bool HAS2, bool AV, bool BV>
+template <int TM, int TN, int REP, bool A_KFAST, bool B_KFAST, bool HAS2, bool AV, bool BV, int BKT = 16>
 __global__ __launch_bounds__(256, (TM * TN == 4 ? 4 : 1)) void tfc_gemm_kernel(const Group g) {
+    constexpr int BK = BKT, KT = KOFF / BK;  // (KT: K tiles whose k offsets are evaluated together)
     constexpr int BM = 64 * TM, BN = 64 * TN, SA = BM + 4, SB = BN + 4;
     constexpr int TILE = BK * SA + BK * SB;
     __shared__ __attribute__((aligned(16))) float tiles[2 * TILE];
@@ -327,8 +336,8 @@ __global__ __launch_bounds__(256, (TM * TN == 4 ? 4 : 1)) void tfc_gemm_kernel(c
     // iteration ago) is moved to LDS and tile i + 2 is requested - a load has two iterations to arrive instead of
     // one (the MFMAs of one 16-deep tile last ~0.2 us, a load from L2 / HBM several times that).  The loop is
     // unrolled by two so that the two register sets keep fixed names.
-    Operand<BM, A_KFAST, HAS2, AV, REP> A0, A1;
-    Operand<BN, B_KFAST, false, BV, 1> B0, B1;
+    Operand<BM, A_KFAST, HAS2, AV, REP, BK> A0, A1;
+    Operand<BN, B_KFAST, false, BV, 1, BK> B0, B1;
     const long rs1 = P.a1_rs, rs2 = P.a2_rs;
     auto request = [&](auto& A, auto& B, int tile) {  // tile: relative index
         const int kb_ = (tile / KT) & 1, ko_ = (tile % KT) * BK;
@@ -726,7 +735,13 @@ int launch_group(Group& g, const Flags& f, float* workspace, long workspace_floa
         long work = 0;
         for (int i = 0; i < g.n; ++i)
             work += cdiv(g.p[i].m, bm) * cdiv(g.p[i].n, bn) * cdiv(g.p[i].k, BK);
-        static const long target = getenv("TFC_GEMM_TARGET_BLOCKS") ? atol(getenv("TFC_GEMM_TARGET_BLOCKS")) : 1024;
+        // (round 3 sweep, ms per step at configs 3 / 5 / 4 - node-side products at 256: 2.76 / 4.21 / -, 384: 2.73 / - / 38.5,
+        // 512: 2.69 / 3.82 / 38.4, 768: 2.73 / - / 38.8, 1024: 2.75 / 3.90 / 38.5; the radial network's, whose outputs are
+        // 10 - 100 x larger, lose at 512 (config 5: 3.94) and gain nothing at 2048: fewer, longer K ranges mean fewer partial
+        // tiles to write and to sum again)
+        static const long target_node = getenv("TFC_GEMM_TARGET_BLOCKS") ? atol(getenv("TFC_GEMM_TARGET_BLOCKS")) : 512;
+        static const long target_mlp = getenv("TFC_GEMM_TARGET_BLOCKS_MLP") ? atol(getenv("TFC_GEMM_TARGET_BLOCKS_MLP")) : 1024;
+        const long target = (tag && !strncmp(tag, "gemm_mlp", 8)) ? target_mlp : target_node;
         const long len = std::max<long>(8, cdiv(work, target));
         long used = 0;
         for (int i = 0; i < g.n; ++i) {
