@@ -251,6 +251,9 @@ __global__ __launch_bounds__(EDGE_BWD_BLOCK) void tfc_edge_bwd_kernel(
 }
 
 // dpos[n] = sum_{e: ei[1,e]=n} dvec[e] - sum_{e: ei[0,e]=n} dvec[e]
+// Sixteen lanes per node: each walks every sixteenth edge of the node's two segments (the loads of a segment are
+// then in flight together instead of one dependent pair after the other: 24 -> 6 us at config 3), and the sixteen
+// partial sums are added in a fixed butterfly, so the result does not depend on the launch.
 __global__ __launch_bounds__(256) void tfc_edge_vec_bwd_kernel(const float* __restrict__ dvec,
                                                                const int* __restrict__ rp_src,
                                                                const int* __restrict__ eid_src,
@@ -258,14 +261,34 @@ __global__ __launch_bounds__(256) void tfc_edge_vec_bwd_kernel(const float* __re
                                                                const int* __restrict__ eid_dst, long n_nodes,
                                                                float* __restrict__ dpos) {
     const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    const long n = t / 3;
-    const int c = (int)(t - 3 * n);
-    if (n >= n_nodes) return;
-    float s = 0.f;
-    for (int k = rp_dst[n]; k < rp_dst[n + 1]; ++k) s += dvec[3 * (long)eid_dst[k] + c];
-    float m = 0.f;
-    for (int k = rp_src[n]; k < rp_src[n + 1]; ++k) m += dvec[3 * (long)eid_src[k] + c];
-    dpos[3 * n + c] = s - m;
+    const long n = t >> 4;
+    const int sub = (int)(t & 15);
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+    if (n < n_nodes) {
+        for (int k = rp_dst[n] + sub, e = rp_dst[n + 1]; k < e; k += 16) {
+            const float* v = dvec + 3 * (long)eid_dst[k];
+            s0 += v[0];
+            s1 += v[1];
+            s2 += v[2];
+        }
+        for (int k = rp_src[n] + sub, e = rp_src[n + 1]; k < e; k += 16) {
+            const float* v = dvec + 3 * (long)eid_src[k];
+            s0 -= v[0];
+            s1 -= v[1];
+            s2 -= v[2];
+        }
+    }
+#pragma unroll
+    for (int o = 8; o >= 1; o >>= 1) {  // (all 64 lanes take part: no early return above)
+        s0 += __shfl_xor(s0, o, 16);
+        s1 += __shfl_xor(s1, o, 16);
+        s2 += __shfl_xor(s2, o, 16);
+    }
+    if (n < n_nodes && sub == 0) {
+        dpos[3 * n + 0] = s0;
+        dpos[3 * n + 1] = s1;
+        dpos[3 * n + 2] = s2;
+    }
 }
 
 
@@ -582,7 +605,7 @@ extern "C" int tfc_edge_vec_bwd(const float* dvec, const int32_t* rp_src, const 
     TFC_REQUIRE(n_nodes >= 0, TFC_EINVAL, "tfc_edge_vec_bwd: negative size");
     if (n_nodes == 0) return TFC_OK;
     TFC_REQUIRE(dvec && rp_src && eid_src && rp_dst && eid_dst && dpos, TFC_EINVAL, "tfc_edge_vec_bwd: null tensor");
-    const long t = 3 * (long)n_nodes;
+    const long t = 16 * (long)n_nodes;  // sixteen lanes per node
     tfc_edge_vec_bwd_kernel<<<(unsigned)((t + 255) / 256), 256, 0, stream>>>(dvec, rp_src, eid_src, rp_dst, eid_dst,
                                                                              (long)n_nodes, dpos);
     TFC_LAUNCH_CHECK("tfc_edge_vec_bwd_kernel");
