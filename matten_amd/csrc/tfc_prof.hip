@@ -5,6 +5,7 @@
 #include "tfc_common.h"
 
 #include <atomic>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <string>
@@ -33,7 +34,19 @@ int name_id(const char* name) {
 
 }  // namespace
 
+// TFC_TRACE_LAUNCHES=1 (debugging aid): every wrapped launch is named on stderr before it is issued and the stream
+// is synchronised behind it (outside graph captures), so that the last name printed before a GPU fault is the
+// kernel that faulted.
+static bool trace_on() {
+    static const bool on = getenv("TFC_TRACE_LAUNCHES") && atoi(getenv("TFC_TRACE_LAUNCHES")) != 0;
+    return on;
+}
+
 int tfc_prof_begin(const char* name, hipStream_t stream) {
+    if (trace_on()) {
+        fprintf(stderr, "[tfc] %s\n", name);
+        fflush(stderr);
+    }
     const int mode = g_enabled.load(std::memory_order_relaxed);
     if (!mode) return -1;
     if (mode == 2 && strncmp(name, "tfc_conv_", 9) != 0) return -1;  // convolution kernels only
@@ -58,6 +71,11 @@ int tfc_prof_begin(const char* name, hipStream_t stream) {
 }
 
 void tfc_prof_end(int idx, hipStream_t stream) {
+    if (trace_on()) {
+        hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(stream, &st) == hipSuccess && st == hipStreamCaptureStatusNone)
+            (void)hipStreamSynchronize(stream);
+    }
     if (idx < 0) return;
     std::lock_guard<std::mutex> lk(g_mu);
     if ((size_t)idx < g_spans.size()) (void)hipEventRecord(g_spans[idx].stop, stream);

@@ -229,6 +229,14 @@ def clear_caches():
         cache.clear()
 
 
+def snapshot_caches():
+    """References to everything the caches hold right now.  A captured step (matten_amd.graphs) keeps one: the
+    addresses of cached tensors it hit during the capture (workspaces of the side stream, orderings, class tables) are
+    baked into its graph, and a later clear_caches() - the next GraphedStep calls it - must not hand their memory to
+    someone else while that graph can still be replayed."""
+    return [list(cache.values()) for cache in _TENSOR_CACHES]
+
+
 def check_edge_orderings(wait: bool = False):
     """Raise IndexError if an edge ordering built earlier saw node ids outside [0, n_nodes).  Only flags that
     have already arrived on the host are looked at unless `wait`."""
@@ -1386,8 +1394,9 @@ def _fctp_bwd(n, x, a, d_a, weight, gt, spec, ins_list, dx=None, dw=None, da=Non
     ins = _fctp_ins(tuple(ins_list))
     L = _lib.lib()
     xt = part = None
-    if da is not None:
+    if da is not None or dw is not None:  # (the channel-contiguous copy of x the weight / attribute gradients contract over)
         xt = torch.empty(max(n * spec.d_x, 1), dtype=torch.float32, device=x.device)
+    if da is not None:
         part = torch.empty(max(len(ins) * n * d_a, 1), dtype=torch.float32, device=x.device)
     ws = _fctp_workspace(ins, n)
     _lib.check(L.tfc_fctp_bwd(ins, len(ins), _ptr(x), _ptr(a), _ptr(weight), None, n, spec.d_x, d_a, spec.d_out, weight.numel(),
