@@ -437,9 +437,7 @@ int tfc_linear_bwd(const tfc_linear_ins* ins, int32_t n_ins, const float* xt, co
  * backward: gout/gt/gt_ready as for tfc_linear_bwd; dx [n_rows, d_x], dw [weight_numel], da
  * [n_rows, d_a] are each optional (null: not computed).  da needs two scratch buffers: xt
  * [n_rows * d_x] (channel-contiguous copy of x, written by the call) and da_part [n_ins * n_rows * d_a]
- * (one partial per instruction, added in instruction order: deterministic).  dw takes xt too when it is
- * given (optional for dw alone): the product then reads x in 16-byte groups along the channels instead
- * of single floats at stride 2l+1, about three times faster at 128 channels.  `workspace`: optional split-K
+ * (one partial per instruction, added in instruction order: deterministic).  `workspace`: optional split-K
  * scratch of tfc_fctp_workspace_floats floats.  The low-rank route of DESIGN.md §4 (attributes that
  * are copies of few rows) is these same calls on the re-associated operands. */
 typedef struct tfc_fctp_ins {

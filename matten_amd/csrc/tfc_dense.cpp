@@ -365,7 +365,6 @@ extern "C" int tfc_fctp_bwd(const tfc_fctp_ins* ins, int32_t n_ins, const float*
     if (rc != TFC_OK) return rc;
     TFC_REQUIRE(gt && (gt_ready || gout), TFC_EINVAL, "tfc_fctp_bwd: null gradient");
     TFC_REQUIRE(!da || (xt && da_part), TFC_EINVAL, "tfc_fctp_bwd: the attribute gradient needs the xt and da_part scratch");
-    TFC_REQUIRE(!xt || n_rows < (1L << 31), TFC_EUNSUPPORTED, "tfc_fctp_bwd: more than 2^31 rows");
     const long n = n_rows;
     if (n == 0) {
         if (dw) TFC_HIP(hipMemsetAsync(dw, 0, sizeof(float) * (size_t)weight_numel, stream));
@@ -447,30 +446,13 @@ extern "C" int tfc_fctp_bwd(const tfc_fctp_ins* ins, int32_t n_ins, const float*
     }
     if (dw) {
         // dW[(u,v), w] = alpha sum_{(n,k)} x[n,u,k] a[n,v] g[n,w,k]; every instruction owns its weight block
-        // With the xt scratch the first factor comes from the channel-contiguous copy, rows ordered (v, u) and the
-        // contraction index (k, n): four consecutive rows share a[n, v] and read xt[k][n][u .. u+3] as one 16-byte
-        // group, where e3nn's layout gives four scattered dwords per group (config 4: 2.0 -> 0.7 ms for this launch).
-        if (xt) {
-            rc = ensure_xt();
-            if (rc != TFC_OK) return rc;
-        }
         std::vector<tfc_gemm_desc> g;
         for (int i = 0; i < n_ins; ++i) {
             const tfc_fctp_ins& q = ins[i];
+            // (the same product from the channel-contiguous copy of x, rows ordered (v, u) so that four rows share
+            // a[n, v] and read 16 bytes of x, was measured in round 3: 271 against 273 us per launch at config 4, and
+            // three more transposing passes per step - not kept)
             tfc_gemm_desc d;
-            if (xt) {
-                const long mu = q.mul_u, mv = q.mul_v, mw = q.mul_w;
-                d = desc(mu * mv, mw, n * q.dim, xt + (long)q.x_off * n, gt + (long)q.out_off * n, dw + q.w_off,
-                         imap(1, (int)mu, 0, 0, 1), lin(mu), lin(mw), lin(1), imap(1, (int)mu, mw, 0, mv * mw), lin(1), q.alpha,
-                         false, "gemm_fctp_dw");
-                d.a2 = a + q.a_off;
-                d.a2_r = imap(1, (int)mu, 1, 0, 0);
-                d.a2_k = imap(1, (int)n, 0, 0, d_a);
-                d.workspace = workspace;
-                d.workspace_floats = workspace ? workspace_floats : 0;
-                g.push_back(d);
-                continue;
-            }
             d = desc((long)q.mul_u * q.mul_v, q.mul_w, n * q.dim, x + q.x_off, gt + (long)q.out_off * n,
                      dw + q.w_off, imap(1, q.mul_v, q.dim, 0, 0), imap(1, q.dim, d_x, 0, 1),
                      imap(1, q.dim, q.mul_w, 0, n * q.mul_w), lin(1), lin(q.mul_w), lin(1), q.alpha, false,

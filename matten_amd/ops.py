@@ -1394,7 +1394,7 @@ def _fctp_bwd(n, x, a, d_a, weight, gt, spec, ins_list, dx=None, dw=None, da=Non
     ins = _fctp_ins(tuple(ins_list))
     L = _lib.lib()
     xt = part = None
-    if da is not None or dw is not None:  # (the channel-contiguous copy of x the weight / attribute gradients contract over)
+    if da is not None:
         xt = torch.empty(max(n * spec.d_x, 1), dtype=torch.float32, device=x.device)
     if da is not None:
         part = torch.empty(max(len(ins) * n * d_a, 1), dtype=torch.float32, device=x.device)
