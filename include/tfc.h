@@ -460,6 +460,20 @@ int tfc_fctp_bwd(const tfc_fctp_ins* ins, int32_t n_ins, const float* x, const f
 int tfc_fctp_class_rows(const float* part, int32_t n_parts, int32_t r, int32_t d_a, const float* inv_count,
                         const int64_t* cls, int64_t n_rows, float* da, tfc_stream_t stream);
 
+/* Weight re-associations of the self connection when the node attributes are rows of a small table (a[n] = rows[cls[n]],
+ * rows [r, d_a], r a multiple of 4; eigenn/nn/embedding.py:59-75): the layer then contracts over
+ *     W'[u, s, w] = sum_v rows[s, a_off + v] W[u, v, w]                      (tfc_fctp_rows_w;  W' block of instruction i at
+ *                                                                             sum_{j<i} mul_u_j r mul_w_j, [mul_u][r][mul_w])
+ * with tfc_fctp_fwd / _bwd on (one-hot classes, W'), and the weight gradient comes back through
+ *     dW[u, v, w]  = sum_s rows[s, a_off + v] dW'[u, s, w]                   (tfc_fctp_rows_dw)
+ * - products with r rows / r terms, one short kernel each instead of a GEMM launch whose tile is 94 % padding.  At most 32
+ * instructions, mul_v <= 256 (otherwise TFC_EUNSUPPORTED: use tfc_gemm_group).  Fixed summation order. */
+int64_t tfc_fctp_rows_numel(const tfc_fctp_ins* ins, int32_t n_ins, int32_t r);
+int tfc_fctp_rows_w(const tfc_fctp_ins* ins, int32_t n_ins, const float* rows, int32_t r, int32_t d_a, const float* weight,
+                    int64_t weight_numel, float* wp, tfc_stream_t stream);
+int tfc_fctp_rows_dw(const tfc_fctp_ins* ins, int32_t n_ins, const float* rows, int32_t r, int32_t d_a, const float* dwp,
+                     int64_t weight_numel, float* dw, tfc_stream_t stream);
+
 /* The class table of node attributes that are rows of a per-class table (eigenn/nn/embedding.py:59-75: NODE_ATTRS =
  * embedding(species), so the classes are the species indices and their number is known): in one call, with no host
  * synchronisation (it runs inside captured steps),

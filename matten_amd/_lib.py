@@ -170,6 +170,9 @@ SIGNATURES = {
     "tfc_gate_bwd": (C.c_int, [C.POINTER(GateSeg), _I32, _P, _P, _I64, _I32, _I32, _P, _P]),
     "tfc_fctp_class_rows": (C.c_int, [_P, _I32, _I32, _I32, _P, _P, _I64, _P, _P]),
     "tfc_class_table": (C.c_int, [_P, _I64, _I32, _I32, _P, _P, _P, _P, _P, _P]),
+    "tfc_fctp_rows_numel": (C.c_int64, [_P, _I32, _I32]),
+    "tfc_fctp_rows_w": (C.c_int, [_P, _I32, _P, _I32, _I32, _P, _I64, _P, _P]),
+    "tfc_fctp_rows_dw": (C.c_int, [_P, _I32, _P, _I32, _I32, _P, _I64, _P, _P]),
     "tfc_gate_fwd_t": (C.c_int, [C.POINTER(GateSeg), _I32, _P, _I64, _I32, _I32, _P, C.POINTER(IrBlock), _I32, _P, _P]),
     "tfc_gate_bwd_t": (C.c_int, [C.POINTER(GateSeg), _I32, _P, _P, _I64, _I32, _I32, _P, C.POINTER(IrBlock), _I32, _P, _P]),
 }

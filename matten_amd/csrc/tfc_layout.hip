@@ -172,6 +172,104 @@ __global__ __launch_bounds__(64) void tfc_class_finish_kernel(const int* __restr
     }
 }
 
+// ---- weight re-associations of the self connection's low-rank route (tfc_fctp_rows_*) ------------------------------
+// With attributes that are rows of a small table R [r, d_a] (a[n] = R[cls[n]]) the self connection contracts over
+// W'[u, s, w] = sum_v R[s, v] W[u, v, w].  W' and dW = R^T dW' are products with r = 4 .. rows / terms: as GEMMs they cost a
+// launch of 13 us each at config 3 (94 % of a 64-row tile is padding), six per step; here they are one short kernel
+// each (config 3: 13 -> 8 us).  Every sum runs in a fixed order.  (dR = dW' . W, r x mul_v outputs of mul_u mul_w terms,
+// was written the same way and measured no faster than its split-K GEMM - 26 against 25 us, 133 against 92 at config
+// 4: every workgroup re-reads all of dW' - and stays a GEMM.)
+constexpr int ROWS_MAX_INS = 32;
+struct RowsIns {
+    int mu, mv, mw, a_off, w_off, p_off;  // p_off: offset of the instruction's block in W' / dW'
+};
+struct RowsArgs {
+    int n, r, d_a;
+    RowsIns q[ROWS_MAX_INS];
+};
+
+// W'[p_off + (u r + s) mw + w] = sum_v R[s, a_off + v] W[w_off + (u mv + v) mw + w];  grid (tiles of 64 (u, w), ins, r / 4)
+// The four waves of a workgroup take a quarter of v each for the same 64 (u, w) pairs (16 - 32 loads per thread, all in
+// flight, and four times as many workgroups as one thread per pair would give); wave 0 adds the quarters in order.
+__global__ __launch_bounds__(256) void tfc_fctp_rows_w_kernel(const RowsArgs A, const float* __restrict__ rows,
+                                                              const float* __restrict__ weight, float* __restrict__ wp) {
+    const RowsIns q = A.q[blockIdx.y];
+    const int s0 = 4 * blockIdx.z;
+    __shared__ float Rl[4][256];
+    __shared__ float part[4][4][64];
+    for (int i = threadIdx.x; i < 4 * q.mv; i += blockDim.x) {
+        const int k = i / q.mv, v = i - k * q.mv;
+        Rl[k][v] = rows[(long)(s0 + k) * A.d_a + q.a_off + v];
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int n_p = q.mu * q.mw;
+    const int p = blockIdx.x * 64 + lane;
+    const int pc = p < n_p ? p : n_p - 1;  // (lanes past the end shadow the last pair: valid addresses, nothing stored)
+    const int u = pc / q.mw, w = pc - u * q.mw;
+    const float* wr = weight + q.w_off + (long)u * q.mv * q.mw + w;
+    const int per = (q.mv + 3) >> 2;
+    const int v0 = wave * per, v1 = min(q.mv, v0 + per);
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    int v = v0;
+    for (; v + 8 <= v1; v += 8) {
+        float x[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) x[j] = wr[(long)(v + j) * q.mw];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            a0 = fmaf(Rl[0][v + j], x[j], a0);
+            a1 = fmaf(Rl[1][v + j], x[j], a1);
+            a2 = fmaf(Rl[2][v + j], x[j], a2);
+            a3 = fmaf(Rl[3][v + j], x[j], a3);
+        }
+    }
+    for (; v < v1; ++v) {
+        const float x = wr[(long)v * q.mw];
+        a0 = fmaf(Rl[0][v], x, a0);
+        a1 = fmaf(Rl[1][v], x, a1);
+        a2 = fmaf(Rl[2][v], x, a2);
+        a3 = fmaf(Rl[3][v], x, a3);
+    }
+    part[wave][0][lane] = a0;
+    part[wave][1][lane] = a1;
+    part[wave][2][lane] = a2;
+    part[wave][3][lane] = a3;
+    __syncthreads();
+    if (wave == 0 && p < n_p) {
+        float* o = wp + q.p_off + ((long)u * A.r + s0) * q.mw + w;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) o[(long)k * q.mw] = ((part[0][k][lane] + part[1][k][lane]) + part[2][k][lane]) + part[3][k][lane];
+    }
+}
+
+// dW[w_off + (u mv + v) mw + w] = sum_s R[s, a_off + v] dW'[p_off + (u r + s) mw + w];  grid (tiles of (u, v, w), ins)
+__global__ __launch_bounds__(256) void tfc_fctp_rows_dw_kernel(const RowsArgs A, const float* __restrict__ rows,
+                                                               const float* __restrict__ dwp, float* __restrict__ dw) {
+    const RowsIns q = A.q[blockIdx.y];
+    const unsigned p = blockIdx.x * blockDim.x + threadIdx.x;  // (32-bit: a weight block has fewer than 2^31 entries)
+    if (p >= (unsigned)(q.mu * q.mv * q.mw)) return;
+    const unsigned t = p / (unsigned)q.mw;
+    const int w = (int)(p - t * (unsigned)q.mw);
+    const int u = (int)(t / (unsigned)q.mv), v = (int)(t - (unsigned)u * (unsigned)q.mv);
+    const float* g = dwp + q.p_off + (long)u * A.r * q.mw + w;
+    const float* rv = rows + q.a_off + v;
+    float acc = 0.f;
+    int s = 0;
+    for (; s + 4 <= A.r; s += 4) {
+        float a[4], b[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            a[j] = rv[(long)(s + j) * A.d_a];
+            b[j] = g[(long)(s + j) * q.mw];
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc = fmaf(a[j], b[j], acc);
+    }
+    for (; s < A.r; ++s) acc = fmaf(rv[(long)s * A.d_a], g[(long)s * q.mw], acc);
+    dw[q.w_off + p] = acc;
+}
+
 }  // namespace
 
 extern "C" int tfc_fctp_class_rows(const float* part, int32_t n_parts, int32_t r, int32_t d_a, const float* inv_count,
@@ -184,6 +282,71 @@ extern "C" int tfc_fctp_class_rows(const float* part, int32_t n_parts, int32_t r
     TfcProfScope prof("tfc_class_rows_kernel", stream);
     tfc_class_rows_kernel<<<grid, 256, 0, stream>>>(part, n_parts, r, d_a, inv_count, cls, (long)n_rows, da);
     TFC_LAUNCH_CHECK("tfc_class_rows_kernel");
+    return TFC_OK;
+}
+
+namespace {
+int rows_args(const tfc_fctp_ins* ins, int n_ins, int r, int d_a, long w_numel, RowsArgs* A, long* wp_numel, int* mv_max,
+              long* uw_max, long* uvw_max, const char* who) {
+    TFC_REQUIRE(ins && n_ins > 0 && n_ins <= ROWS_MAX_INS, TFC_EUNSUPPORTED, "%s: 1 .. %d instructions, got %d", who, ROWS_MAX_INS,
+                n_ins);
+    TFC_REQUIRE(r >= 4 && r % 4 == 0 && d_a > 0, TFC_EINVAL, "%s: r must be a positive multiple of 4", who);
+    A->n = n_ins, A->r = r, A->d_a = d_a;
+    long off = 0;
+    *mv_max = 0, *uw_max = 0, *uvw_max = 0;
+    for (int i = 0; i < n_ins; ++i) {
+        const tfc_fctp_ins& q = ins[i];
+        TFC_REQUIRE(q.mul_u > 0 && q.mul_v > 0 && q.mul_v <= 256 && q.mul_w > 0, TFC_EUNSUPPORTED,
+                    "%s: instruction %d: multiplicities must be positive, second input at most 256", who, i);
+        TFC_REQUIRE(q.a_off >= 0 && q.a_off + q.mul_v <= d_a, TFC_EINVAL, "%s: instruction %d reads outside the attribute row", who, i);
+        TFC_REQUIRE(q.w_off >= 0 && (long)q.w_off + (long)q.mul_u * q.mul_v * q.mul_w <= w_numel, TFC_EINVAL,
+                    "%s: instruction %d reads outside the weights", who, i);
+        TFC_REQUIRE(off + (long)q.mul_u * r * q.mul_w < (1L << 31), TFC_EUNSUPPORTED, "%s: table too large", who);
+        A->q[i] = RowsIns{q.mul_u, q.mul_v, q.mul_w, q.a_off, q.w_off, (int)off};
+        off += (long)q.mul_u * r * q.mul_w;
+        *mv_max = std::max(*mv_max, q.mul_v);
+        *uw_max = std::max(*uw_max, (long)q.mul_u * q.mul_w);
+        *uvw_max = std::max(*uvw_max, (long)q.mul_u * q.mul_v * q.mul_w);
+    }
+    *wp_numel = off;
+    return TFC_OK;
+}
+}  // namespace
+
+extern "C" int64_t tfc_fctp_rows_numel(const tfc_fctp_ins* ins, int32_t n_ins, int32_t r) {
+    if (!ins || n_ins <= 0 || r <= 0) return -1;
+    int64_t off = 0;
+    for (int i = 0; i < n_ins; ++i) off += (int64_t)ins[i].mul_u * r * ins[i].mul_w;
+    return off;
+}
+
+extern "C" int tfc_fctp_rows_w(const tfc_fctp_ins* ins, int32_t n_ins, const float* rows, int32_t r, int32_t d_a,
+                               const float* weight, int64_t weight_numel, float* wp, tfc_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    RowsArgs A;
+    long n_wp, uw, uvw;
+    int mv;
+    const int rc = rows_args(ins, n_ins, r, d_a, weight_numel, &A, &n_wp, &mv, &uw, &uvw, "tfc_fctp_rows_w");
+    if (rc) return rc;
+    TFC_REQUIRE(rows && weight && wp, TFC_EINVAL, "tfc_fctp_rows_w: null tensor");
+    TfcProfScope prof("gemm_fctp_lowrank_w", stream);
+    tfc_fctp_rows_w_kernel<<<dim3((unsigned)((uw + 63) / 64), n_ins, r / 4), 256, 0, stream>>>(A, rows, weight, wp);
+    TFC_LAUNCH_CHECK("tfc_fctp_rows_w_kernel");
+    return TFC_OK;
+}
+
+extern "C" int tfc_fctp_rows_dw(const tfc_fctp_ins* ins, int32_t n_ins, const float* rows, int32_t r, int32_t d_a,
+                                const float* dwp, int64_t weight_numel, float* dw, tfc_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    RowsArgs A;
+    long n_wp, uw, uvw;
+    int mv;
+    const int rc = rows_args(ins, n_ins, r, d_a, weight_numel, &A, &n_wp, &mv, &uw, &uvw, "tfc_fctp_rows_dw");
+    if (rc) return rc;
+    TFC_REQUIRE(rows && dwp && dw, TFC_EINVAL, "tfc_fctp_rows_dw: null tensor");
+    TfcProfScope prof("gemm_fctp_lowrank_w", stream);
+    tfc_fctp_rows_dw_kernel<<<dim3((unsigned)((uvw + 255) / 256), n_ins), 256, 0, stream>>>(A, rows, dwp, dw);
+    TFC_LAUNCH_CHECK("tfc_fctp_rows_dw_kernel");
     return TFC_OK;
 }
 

@@ -1525,6 +1525,60 @@ def attr_factors(a: torch.Tensor, classes: Optional[torch.Tensor] = None):
     return res
 
 
+def _rows_kernels_ok(spec) -> bool:
+    # (measured: 9.5 against 13.4 us per launch at config 3, 1.6 M weights; 58 against 42 us at config 4, 16.8 M weights,
+    # where the GEMM's tiles are no longer mostly padding - the short kernels are taken below 4 M weights)
+    return (len(spec.instructions) <= 32 and all(ins[3] <= 256 for ins in spec.instructions)
+            and spec.weight_numel <= (1 << 22))
+
+
+def _lowrank_w(spec, low_ins, R, r, weight, wp):
+    """W'[u, s, w] = sum_v R[s, v] W[u, v, w] per instruction (tfc_fctp_rows_w: one short launch; a grouped GEMM with r-row
+    tiles beyond the kernel's limits)."""
+    if _rows_kernels_ok(spec):
+        c_ins = _fctp_ins(tuple(spec.instructions))
+        _lib.check(_lib.lib().tfc_fctp_rows_w(c_ins, len(c_ins), _ptr(R), r, spec.d_a, _ptr(weight), weight.numel(), _ptr(wp), _stream()))
+        return
+    _gemm_group([
+        _desc(
+            r, mu * mw, mv, _p(R, ao), _p(weight, wo), _p(wp, lo[7]),
+            a1_r=_lin(spec.d_a), a1_k=_lin(1), b_k=_lin(mw), b_j=_imap(1, mw, mv * mw, 0, 1),
+            c_r=_lin(mw), c_j=_imap(1, mw, r * mw, 0, 1), tag=b"gemm_fctp_lowrank_w",
+        )
+        for (xo, mu, ao, mv, oo, mw, d, wo, alpha), lo in zip(spec.instructions, low_ins)
+    ])
+
+
+def _lowrank_dw(spec, low_ins, R, r, dwp, dw):
+    """dW[u, v, w] = sum_s R[s, v] dW'[u, s, w] (tfc_fctp_rows_dw)."""
+    if _rows_kernels_ok(spec):
+        c_ins = _fctp_ins(tuple(spec.instructions))
+        _lib.check(_lib.lib().tfc_fctp_rows_dw(c_ins, len(c_ins), _ptr(R), r, spec.d_a, _ptr(dwp), dw.numel(), _ptr(dw), _stream()))
+        return
+    _gemm_group([
+        _desc(
+            mv, mu * mw, r, _p(R, ao), _p(dwp, lo[7]), _p(dw, wo),
+            a1_r=_lin(1), a1_k=_lin(spec.d_a), b_k=_lin(mw), b_j=_imap(1, mw, r * mw, 0, 1),
+            c_r=_lin(mw), c_j=_imap(1, mw, mv * mw, 0, 1), tag=b"gemm_fctp_lowrank_w",
+        )
+        for (xo, mu, ao, mv, oo, mw, d, wo, alpha), lo in zip(spec.instructions, low_ins)
+    ])
+
+
+def _lowrank_da(spec, low_ins, r, dwp, weight, part):
+    """part[i, s, v] = sum_{u,w} dW'[u, s, w] W[u, v, w]: the gradient of the distinct rows, per instruction (a split-K GEMM:
+    a dedicated kernel was measured no faster, csrc/tfc_layout.hip)."""
+    _gemm_group([
+        _desc(
+            r, mv, mu * mw, _p(dwp, lo[7]), _p(weight, wo), _p(part, i * r * spec.d_a + ao),
+            a1_r=_lin(mw), a1_k=_imap(1, mw, r * mw, 0, 1),
+            b_k=_imap(1, mw, mv * mw, 0, 1), b_j=_lin(mw), c_r=_lin(spec.d_a), c_j=_lin(1),
+            tag=b"gemm_fctp_da_rows",
+        )
+        for i, ((xo, mu, ao, mv, oo, mw, d, wo, alpha), lo) in enumerate(zip(spec.instructions, low_ins))
+    ])
+
+
 class _FctpFn(torch.autograd.Function):
     """FullyConnectedTensorProduct(x, a) with scalar second input (the self connection).
 
@@ -1564,14 +1618,7 @@ class _FctpFn(torch.autograd.Function):
                 low_ins.append((xo, mu, 0, r, oo, mw, d, off, alpha))
                 off += mu * r * mw
             wp = torch.empty(max(off, 1), dtype=torch.float32, device=x.device)
-            _gemm_group([
-                _desc(
-                    r, mu * mw, mv, _p(R, ao), _p(weight, wo), _p(wp, lo[7]),
-                    a1_r=_lin(spec.d_a), a1_k=_lin(1), b_k=_lin(mw), b_j=_imap(1, mw, mv * mw, 0, 1),
-                    c_r=_lin(mw), c_j=_imap(1, mw, r * mw, 0, 1), tag=b"gemm_fctp_lowrank_w",
-                )
-                for (xo, mu, ao, mv, oo, mw, d, wo, alpha), lo in zip(spec.instructions, low_ins)
-            ])
+            _lowrank_w(spec, low_ins, R, r, weight, wp)
             _fctp_fwd(n, x, Cm, r, wp, out, spec, low_ins, on_base)
             ctx.save_for_backward(x, a, weight, Cm, R, wp)
             ctx.low = tuple(low_ins)
@@ -1620,14 +1667,7 @@ class _FctpFn(torch.autograd.Function):
             if ctx.needs_input_grad[2]:
                 # dW[u, v, w] = sum_s R[s, v] dW'[u, s, w]
                 dw = torch.empty_like(weight)
-                _gemm_group([
-                    _desc(
-                        mv, mu * mw, r, _p(R, ao), _p(dwp, lo[7]), _p(dw, wo),
-                        a1_r=_lin(1), a1_k=_lin(spec.d_a), b_k=_lin(mw), b_j=_imap(1, mw, r * mw, 0, 1),
-                        c_r=_lin(mw), c_j=_imap(1, mw, mv * mw, 0, 1), tag=b"gemm_fctp_lowrank_w",
-                    )
-                    for (xo, mu, ao, mv, oo, mw, d, wo, alpha), lo in zip(spec.instructions, ctx.low)
-                ])
+                _lowrank_dw(spec, ctx.low, R, r, dwp, dw)
             if project_da:
                 # dR[s, v] = sum_{u,w} dW'[u, s, w] W[u, v, w]: the gradient of the distinct rows; every row
                 # of a class then receives its class mean (sums back to dR through any lookup a = R[class])
@@ -1635,15 +1675,7 @@ class _FctpFn(torch.autograd.Function):
                 part = torch.empty(ni, r, spec.d_a, dtype=torch.float32, device=x.device)
                 if not spec.a_covered or any(ins[3] != spec.d_a for ins in spec.instructions):
                     part.zero_()
-                _gemm_group([
-                    _desc(
-                        r, mv, mu * mw, _p(dwp, lo[7]), _p(weight, wo), _p(part, i * r * spec.d_a + ao),
-                        a1_r=_lin(mw), a1_k=_imap(1, mw, r * mw, 0, 1),
-                        b_k=_imap(1, mw, mv * mw, 0, 1), b_j=_lin(mw), c_r=_lin(spec.d_a), c_j=_lin(1),
-                        tag=b"gemm_fctp_da_rows",
-                    )
-                    for i, ((xo, mu, ao, mv, oo, mw, d, wo, alpha), lo) in enumerate(zip(spec.instructions, ctx.low))
-                ])
+                _lowrank_da(spec, ctx.low, r, dwp, weight, part)
                 da = torch.empty(n, spec.d_a, dtype=torch.float32, device=x.device)
                 _lib.check(_lib.lib().tfc_fctp_class_rows(_ptr(part), ni, r, spec.d_a, _ptr(ctx.factors.inv_count),
                                                           _ptr(ctx.factors.inv), n, _ptr(da), _stream()))

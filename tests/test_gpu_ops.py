@@ -1233,3 +1233,47 @@ def test_class_table_matches_its_definition(device):
     assert torch.equal(Cm3.cpu(), ref3) and torch.equal(inv3.cpu(), 1.0 / ref3.sum(0).clamp_min(1.0))
     first = torch.full((r3,), 5000, dtype=torch.int64).scatter_reduce_(0, big, torch.arange(5000), reduce="amin")
     assert torch.equal(idx3.cpu(), torch.where(first < 5000, first, torch.zeros_like(first)))
+
+
+def test_fctp_rows_entry_points_match_their_definition(device):
+    """tfc_fctp_rows_w / _dw (weight re-associations of the low-rank self connection) through the C ABI against
+    einsum in fp64, on instructions of different sizes with an attribute block that does not start at column 0."""
+    import ctypes as C
+
+    from matten_amd import _lib, ops
+
+    g = torch.Generator().manual_seed(11)
+    r, d_a = 8, 40
+    # (x_off, mul_u, a_off, mul_v, out_off, mul_w, dim, w_off, alpha)
+    ins, w_off = [], 0
+    for mu, ao, mv, mw in ((16, 0, 24, 12), (8, 24, 16, 64), (5, 0, 40, 7)):
+        ins.append((0, mu, ao, mv, 0, mw, 1, w_off, 1.0))
+        w_off += mu * mv * mw
+    rows = torch.randn(r, d_a, generator=g).to(device)
+    weight = torch.randn(w_off, generator=g).to(device)
+    L = _lib.lib()
+    c_ins = ops._fctp_ins(tuple(ins))
+    n_wp = int(L.tfc_fctp_rows_numel(c_ins, len(c_ins), r))
+    assert n_wp == sum(mu * r * mw for _, mu, _, _, _, mw, _, _, _ in ins)
+    wp = torch.full((n_wp,), float("nan"), device=device)
+    _lib.check(L.tfc_fctp_rows_w(c_ins, len(c_ins), ops._ptr(rows), r, d_a, ops._ptr(weight), weight.numel(), ops._ptr(wp), ops._stream()))
+    dwp = torch.randn(n_wp, generator=g).to(device)
+    dw = torch.full((w_off,), float("nan"), device=device)
+    _lib.check(L.tfc_fctp_rows_dw(c_ins, len(c_ins), ops._ptr(rows), r, d_a, ops._ptr(dwp), dw.numel(), ops._ptr(dw), ops._stream()))
+    torch.cuda.synchronize()
+    p_off = 0
+    for i, (_, mu, ao, mv, _, mw, _, wo, _) in enumerate(ins):
+        W = weight[wo : wo + mu * mv * mw].view(mu, mv, mw).double().cpu()
+        R = rows[:, ao : ao + mv].double().cpu()
+        ref_wp = torch.einsum("sv,uvw->usw", R, W)
+        got_wp = wp[p_off : p_off + mu * r * mw].view(mu, r, mw).double().cpu()
+        assert (got_wp - ref_wp).abs().max() <= 1e-5 * ref_wp.abs().max(), i
+        G = dwp[p_off : p_off + mu * r * mw].view(mu, r, mw).double().cpu()
+        ref_dw = torch.einsum("sv,usw->uvw", R, G)
+        got_dw = dw[wo : wo + mu * mv * mw].view(mu, mv, mw).double().cpu()
+        assert (got_dw - ref_dw).abs().max() <= 1e-5 * ref_dw.abs().max(), i
+        p_off += mu * r * mw
+    # limits are refused, not overrun
+    many = ops._fctp_ins(tuple((0, 4, 0, 4, 0, 4, 1, 0, 1.0) for _ in range(33)))
+    assert L.tfc_fctp_rows_w(many, 33, ops._ptr(rows), r, d_a, ops._ptr(weight), weight.numel(), ops._ptr(wp), ops._stream()) != 0
+    assert L.tfc_fctp_rows_w(c_ins, len(c_ins), ops._ptr(rows), 6, d_a, ops._ptr(weight), weight.numel(), ops._ptr(wp), ops._stream()) != 0
