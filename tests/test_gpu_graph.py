@@ -136,3 +136,56 @@ def test_replay_refuses_a_changed_topology(device):
         b0[K.EDGE_INDEX].copy_(b0[K.EDGE_INDEX].flip(0))
     with pytest.raises(RuntimeError, match="topology"):
         replay()
+
+
+def test_an_earlier_graph_survives_the_capture_of_a_later_one(device):
+    """A GraphedStep clears the ops' caches when it is built.  Tensors an EARLIER graph reads at captured addresses (the
+    side stream's workspaces, made in its warm-up) must outlive that: the earlier graph keeps them (ops.snapshot_caches)
+    and replays to the bits of the eager step after two later captures and eager steps in between."""
+    from matten_amd import keys as K
+    from matten_amd.graphs import GraphedStep
+    from tests.parity import CONFIGS, Stack, _prep, make_batch
+
+    cfg = CONFIGS["minimal"]
+    torch.manual_seed(35)
+    b0 = _prep(make_batch(cfg), str(device), torch.float32)
+    other = _prep(make_batch(CONFIGS["smoke"], seed0=77), str(device), torch.float32)
+    model = Stack("hip", cfg).to(device)
+    model2 = Stack("hip", CONFIGS["smoke"]).to(device)
+    params = list(model.parameters())
+
+    def run(m, b, n_graphs):
+        for p in m.parameters():
+            p.grad = None
+        b = dict(b)
+        pos = b[K.POSITIONS].detach().requires_grad_(True)
+        b[K.POSITIONS] = pos
+        _, energy, _ = m(b, n_graphs)
+        energy.sum().backward()
+        return energy.detach(), pos.grad, [p.grad for p in m.parameters()]
+
+    first = GraphedStep(lambda: run(model, b0, cfg["graphs"]))
+    ref = [t.clone() for t in (lambda o: [o[0], o[1]] + o[2])(first())]
+    # two more captures (each drops every cache), with eager work that reuses whatever memory was handed back
+    for _ in range(2):
+        later = GraphedStep(lambda: run(model2, other, CONFIGS["smoke"]["graphs"]))
+        later()
+        run(model2, other, CONFIGS["smoke"]["graphs"])
+        junk = [torch.full((1 << 22,), float("nan"), device=device) for _ in range(8)]  # noqa: F841 (fills freed blocks)
+        del junk
+    torch.cuda.synchronize()
+    got = (lambda o: [o[0], o[1]] + o[2])(first())
+    torch.cuda.synchronize()
+    for a, b in zip(got, ref):
+        assert torch.equal(a, b)
+    assert params and got[1].abs().max().item() > 0
+
+
+def test_rebuild_topology_is_refused_on_one_stream(device, monkeypatch):
+    """Known issue: the combination faults at config 4's size; it is refused before anything is captured."""
+    from matten_amd import ops
+    from matten_amd.graphs import GraphedStep
+
+    monkeypatch.setattr(ops, "MLP_SIDE_STREAM", False)
+    with pytest.raises(RuntimeError, match="TFC_MLP_SIDE_STREAM"):
+        GraphedStep(lambda: None, rebuild_topology=True)
