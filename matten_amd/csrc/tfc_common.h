@@ -30,6 +30,12 @@ int tfc_set_error(int code, const char* fmt, ...);
             return tfc_set_error(TFC_ELAUNCH, "launch of %s failed: %s", name, hipGetErrorString(_e)); \
     } while (0)
 
+// Zero-fill of `bytes` (a multiple of 4) on `stream`, as a KERNEL (tfc_layout.hip).  Not hipMemsetAsync: a memset node of a
+// captured graph that is one chain of nodes (a step captured on one stream) was seen to replay with another byte value
+// from the second replay on (ROCm 7.2, gfx950; tools/selftest/graph_memset_probe.py: 0x10.., 0x40.. instead of 0) - in
+// tfc_csr_build that turns the counts, and with them every edge index, into garbage.
+int tfc_zero_async(void* p, size_t bytes, hipStream_t stream);
+
 // opt-in per-kernel timing (tfc_prof.hip): events on the launch stream around a launch
 int tfc_prof_begin(const char* name, hipStream_t stream);
 void tfc_prof_end(int idx, hipStream_t stream);

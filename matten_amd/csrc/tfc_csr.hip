@@ -154,8 +154,8 @@ static int csr_build_impl(const int64_t* key, const int64_t* other, int64_t n_ed
                           hipStream_t stream) {
     int* cursor = workspace;
     int* tmp = cursor + n_nodes + 1;
-    TFC_HIP(hipMemsetAsync(row_ptr, 0, (size_t)(n_nodes + 1) * sizeof(int32_t), stream));
-    TFC_HIP(hipMemsetAsync(status, 0, sizeof(int32_t), stream));
+    { const int zrc = tfc_zero_async(row_ptr, (size_t)(n_nodes + 1) * sizeof(int32_t), stream); if (zrc != TFC_OK) return zrc; }
+    { const int zrc = tfc_zero_async(status, sizeof(int32_t), stream); if (zrc != TFC_OK) return zrc; }
     if (n_edges == 0 || n_nodes == 0) return TFC_OK;
     const int eg = (int)std::min<long>((n_edges + 255) / 256, 4096);
     tfc_csr_count_kernel<<<eg, 256, 0, stream>>>(key, other, (long)n_edges, (long)n_nodes, row_ptr, status);

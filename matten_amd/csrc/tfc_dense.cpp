@@ -147,7 +147,7 @@ extern "C" int tfc_linear_bwd(const tfc_linear_ins* ins, int32_t n_ins, const fl
     TFC_REQUIRE(!dx || weight, TFC_EINVAL, "tfc_linear_bwd: null weights");
     const long n = n_rows;
     if (n == 0) {
-        if (dw) TFC_HIP(hipMemsetAsync(dw, 0, sizeof(float) * (size_t)weight_numel, stream));
+        if (dw) { const int zrc = tfc_zero_async(dw, sizeof(float) * (size_t)weight_numel, stream); if (zrc != TFC_OK) return zrc; }
         return TFC_OK;
     }
     if (!gt_ready) {
@@ -212,7 +212,7 @@ extern "C" int tfc_radial_mlp_bwd(const float* x, int64_t n_rows, int32_t n_laye
     if (E == 0) {
         for (int i = 0; i < n_layers; ++i)
             if (dweights[i])
-                TFC_HIP(hipMemsetAsync(dweights[i], 0, sizeof(float) * (size_t)dims[i] * dims[i + 1], (hipStream_t)stream));
+                { const int zrc = tfc_zero_async(dweights[i], sizeof(float) * (size_t)dims[i] * dims[i + 1], (hipStream_t)stream); if (zrc != TFC_OK) return zrc; }
         return TFC_OK;
     }
     TFC_REQUIRE(x && gout, TFC_EINVAL, "tfc_radial_mlp_bwd: null tensor");
@@ -367,7 +367,7 @@ extern "C" int tfc_fctp_bwd(const tfc_fctp_ins* ins, int32_t n_ins, const float*
     TFC_REQUIRE(!da || (xt && da_part), TFC_EINVAL, "tfc_fctp_bwd: the attribute gradient needs the xt and da_part scratch");
     const long n = n_rows;
     if (n == 0) {
-        if (dw) TFC_HIP(hipMemsetAsync(dw, 0, sizeof(float) * (size_t)weight_numel, stream));
+        if (dw) { const int zrc = tfc_zero_async(dw, sizeof(float) * (size_t)weight_numel, stream); if (zrc != TFC_OK) return zrc; }
         return TFC_OK;
     }
     TFC_REQUIRE(x && a && weight, TFC_EINVAL, "tfc_fctp_bwd: null tensor");
@@ -408,7 +408,7 @@ extern "C" int tfc_fctp_bwd(const tfc_fctp_ins* ins, int32_t n_ins, const float*
         // [n_rows, d_a] in one grouped launch, the partials are then added in instruction order
         rc = ensure_xt();
         if (rc != TFC_OK) return rc;
-        TFC_HIP(hipMemsetAsync(da_part, 0, sizeof(float) * (size_t)n_ins * n * d_a, stream));
+        { const int zrc = tfc_zero_async(da_part, sizeof(float) * (size_t)n_ins * n * d_a, stream); if (zrc != TFC_OK) return zrc; }
         std::vector<tfc_gemm_desc> g;
         for (int i = 0; i < n_ins; ++i) {
             const tfc_fctp_ins& q = ins[i];

@@ -554,7 +554,7 @@ extern "C" int tfc_edge_encode_bwd(const float* vec, const float* len, int64_t n
     TFC_REQUIRE(!dbw_partial || demb, TFC_EINVAL, "tfc_edge_encode_bwd: dbw without demb");
     const int grid = (int)tfc_edge_bwd_blocks(n_edges);
     if (n_edges == 0) {
-        if (dbw_partial) TFC_HIP(hipMemsetAsync(dbw_partial, 0, sizeof(float) * n_basis, stream));
+        if (dbw_partial) { const int zrc = tfc_zero_async(dbw_partial, sizeof(float) * n_basis, stream); if (zrc != TFC_OK) return zrc; }
         return TFC_OK;
     }
     TFC_REQUIRE(vec && dvec, TFC_EINVAL, "tfc_edge_encode_bwd: null tensor");
@@ -627,7 +627,7 @@ extern "C" int tfc_edge_encode_bwd2(const float* vec, int64_t n_edges, int32_t l
                 "tfc_edge_encode_bwd2: a cotangent is asked for an input that was not given");
     const int grid = (int)tfc_edge_bwd_blocks(n_edges);
     if (n_edges == 0) {
-        if (g_bw_partial) TFC_HIP(hipMemsetAsync(g_bw_partial, 0, sizeof(float) * n_basis, stream));
+        if (g_bw_partial) { const int zrc = tfc_zero_async(g_bw_partial, sizeof(float) * n_basis, stream); if (zrc != TFC_OK) return zrc; }
         return TFC_OK;
     }
     TFC_REQUIRE(vec, TFC_EINVAL, "tfc_edge_encode_bwd2: null tensor");

@@ -370,6 +370,23 @@ extern "C" int tfc_class_table(const int64_t* cls, int64_t n_rows, int32_t n_cla
     return TFC_OK;
 }
 
+// internal: zero-fill by a kernel (see tfc_common.h for why not a memset)
+namespace {
+__global__ __launch_bounds__(256) void tfc_zero_kernel(uint32_t* __restrict__ p, long n_words) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n_words; i += (long)gridDim.x * blockDim.x) p[i] = 0u;
+}
+}  // namespace
+
+int tfc_zero_async(void* p, size_t bytes, hipStream_t stream) {
+    if (bytes == 0) return TFC_OK;
+    TFC_REQUIRE(p && bytes % 4 == 0 && ((uintptr_t)p & 3) == 0, TFC_EINVAL, "tfc_zero_async: %zu bytes at %p", bytes, p);
+    const long n_words = (long)(bytes / 4);
+    const int grid = (int)std::min<long>((n_words + 255) / 256, 4096);
+    tfc_zero_kernel<<<grid, 256, 0, stream>>>((uint32_t*)p, n_words);
+    TFC_LAUNCH_CHECK("tfc_zero_kernel");
+    return TFC_OK;
+}
+
 // internal (tfc_dense.cpp): ordered sum of n_parts slabs of numel floats
 int tfc_sum_parts(const float* part, int n_parts, long numel, float* out, hipStream_t stream) {
     if (numel <= 0 || n_parts <= 0) return TFC_OK;

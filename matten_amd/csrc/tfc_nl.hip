@@ -231,7 +231,7 @@ extern "C" int tfc_nl_count(const double* pos, const int32_t* node_graph, const 
                             "tfc_nl_count");
     if (rc) return rc;
     TFC_REQUIRE(row_ptr, TFC_EINVAL, "tfc_nl_count: null output");
-    TFC_HIP(hipMemsetAsync(row_ptr, 0, (size_t)(n_nodes + 1) * sizeof(int32_t), stream));
+    { const int zrc = tfc_zero_async(row_ptr, (size_t)(n_nodes + 1) * sizeof(int32_t), stream); if (zrc != TFC_OK) return zrc; }
     if (n_nodes == 0) return TFC_OK;
     const NlArgs a{pos, node_graph, graph_ptr, shift_ptr, shifts, shift_vec, graph_box, (long)n_nodes, r_max,
                    r_max * r_max * (1.0 + 1e-12)};
@@ -275,7 +275,7 @@ extern "C" int tfc_nl_ordering(const int64_t* edge_index, const int32_t* row_ptr
     TFC_REQUIRE(n_edges < (1LL << 31) - 1 && n_nodes < (1LL << 31) - 1, TFC_EUNSUPPORTED,
                 "tfc_nl_ordering: more than 2^31 nodes or edges");
     TFC_REQUIRE(status, TFC_EINVAL, "tfc_nl_ordering: null status");
-    TFC_HIP(hipMemsetAsync(status, 0, sizeof(int32_t), stream));
+    { const int zrc = tfc_zero_async(status, sizeof(int32_t), stream); if (zrc != TFC_OK) return zrc; }
     if (n_edges == 0) return TFC_OK;
     TFC_REQUIRE(edge_index && row_ptr && src_eid && src_nbr && dst_eid && dst_nbr, TFC_EINVAL,
                 "tfc_nl_ordering: null tensor");

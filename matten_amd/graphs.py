@@ -41,12 +41,6 @@ class GraphedStep:
 
         self.fn = fn
         self.rebuild_topology = bool(rebuild_topology)
-        if self.rebuild_topology and not ops.MLP_SIDE_STREAM:
-            # KNOWN ISSUE (round 3): with TFC_MLP_SIDE_STREAM=0 a graph captured with its topology
-            # replays its own batch, and then takes an illegal memory access on the replay that follows the first copy-in
-            # of another batch at config 4's size (the default two-stream capture replays the same batches to the bits of
-            # the eager step).  The cause was not found; the combination is refused rather than left to fault.
-            raise RuntimeError("GraphedStep(rebuild_topology=True) is not supported together with TFC_MLP_SIDE_STREAM=0")
         ops.clear_caches()  # (also synchronises the device)
         point_conv.reset_prefetch_state()
         cur = torch.cuda.current_stream()

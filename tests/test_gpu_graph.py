@@ -181,11 +181,47 @@ def test_an_earlier_graph_survives_the_capture_of_a_later_one(device):
     assert params and got[1].abs().max().item() > 0
 
 
-def test_rebuild_topology_is_refused_on_one_stream(device, monkeypatch):
-    """Known issue: the combination faults at config 4's size; it is refused before anything is captured."""
+def test_rebuilt_topology_graph_on_one_stream(device, monkeypatch):
+    """The step captured on ONE stream (TFC_MLP_SIDE_STREAM=0) with its topology: such a graph is a single chain of nodes, in
+    which a hipMemsetAsync node was seen to replay with a garbage byte value from the second replay on (ROCm 7.2;
+    tools/selftest/graph_memset_probe.py) - tfc_csr_build zeroed its counts that way and the second batch took an illegal
+    memory access at config 4.  The library zeroes with a kernel now: two further batches replay to the bits of the eager step."""
+    from matten_amd import keys as K
     from matten_amd import ops
-    from matten_amd.graphs import GraphedStep
+    from matten_amd.data.crystal import pad_null_edges
+    from matten_amd.graphs import GraphedStep, PackedBatch
+    from matten_amd.nn import point_conv
+    from tests.parity import CONFIGS, Stack, _prep, make_batch
 
     monkeypatch.setattr(ops, "MLP_SIDE_STREAM", False)
-    with pytest.raises(RuntimeError, match="TFC_MLP_SIDE_STREAM"):
-        GraphedStep(lambda: None, rebuild_topology=True)
+    point_conv.reset_prefetch_state()
+    cfg = CONFIGS["c3_lowrank"]
+    torch.manual_seed(35)
+    raw = [make_batch(cfg, seed0=1000 + 100 * i) for i in range(3)]
+    e_pad = max(int(b[K.EDGE_INDEX].shape[1]) for b in raw) + 5
+    batches = [_prep(pad_null_edges(b, e_pad), str(device), torch.float32) for b in raw]
+    model = Stack("hip", cfg).to(device)
+    params = list(model.parameters())
+    packed_static = PackedBatch(batches[0])
+    packed = [PackedBatch(b, like=packed_static) for b in batches]
+    static = packed_static.tensors
+
+    def run(b):
+        for p in params:
+            p.grad = None
+        b = dict(b)
+        pos = b[K.POSITIONS].detach().requires_grad_(True)
+        b[K.POSITIONS] = pos
+        _, energy, _ = model(b, cfg["graphs"])
+        energy.sum().backward()
+        return [energy.detach(), pos.grad] + [p.grad for p in params]
+
+    replay = GraphedStep(lambda: run(static), rebuild_topology=True)
+    for i in (0, 0, 1, 2, 1):  # (the same batch twice first: the second replay is where a stale memset shows)
+        packed_static.load(packed[i])
+        got = [t.clone() for t in replay()]
+        ref = run(batches[i])
+        torch.cuda.synchronize()
+        for a, b in zip(got, ref):
+            assert torch.equal(a, b), i
+    point_conv.reset_prefetch_state()
