@@ -820,11 +820,12 @@ int tfc_radial_mlp_bwd_chain(int64_t n_rows, int32_t n_layers, const int32_t* di
     }
     static const int forced = getenv("TFC_MLP_BWD_RB") ? atoi(getenv("TFC_MLP_BWD_RB")) : 0;
     // 128- or 64-edge workgroups: the MFMA time of a CU is set by the edges it owns, so take the size whose
-    // busiest CU owns fewer (two 128-edge or four 64-edge workgroups resident per CU); a tie goes to 128,
-    // which streams W_L half as often
+    // busiest CU owns fewer (two 128-edge or four 64-edge workgroups resident per CU); a tie goes to 64: twice
+    // as many workgroups hide the latency of the gout stream better than the halved W_L traffic (L2-resident) is
+    // worth (each kernel alone: config 3 126 -> 114 us, config 5 205 -> 179, config 4 1259 -> 1161)
     const long nb128 = (n_rows + 127) / 128, nb64 = (n_rows + 63) / 64;
     const long cost128 = (nb128 + 255) / 256 * 128, cost64 = (nb64 + 255) / 256 * 64;
-    const bool small = forced ? forced == 64 : cost64 < cost128;
+    const bool small = forced ? forced == 64 : cost64 <= cost128;
     const long nb = small ? nb64 : nb128;
     TFC_REQUIRE(nb < (1LL << 31), TFC_EUNSUPPORTED, "tfc_radial_mlp_bwd: grid too large");
     TfcProfScope prof("mlp_fused_bwd", stream);
